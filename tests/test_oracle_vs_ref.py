@@ -1,0 +1,33 @@
+"""CPU, build container only: fuzz the oracle against the real reference engines (oracle/_ref).
+Skipped where oracle/_ref/ref_harness does not exist."""
+import numpy as np
+import pytest
+
+import refrun
+import synth
+from oracle import pmoracle as O
+
+CONFIGS = [(0, 0, 1), (4, 0, 1), (2, 0, 1), (100, 1, 0), (100, 2, 0), (100, 2, 1), (5, 1, 1), (5, 2, 0), (5, 2, 1),
+           (12, 1, 0), (12, 1, 1), (14, 1, 1), (12, 2, 1), (0, 1, 1), (0, 1, 0), (0, 2, 1), (0, 2, 0)]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_against_reference(ref_harness, seed):
+    rng = np.random.default_rng(1000 + seed)
+    ents = synth.make_entries(rng, int(rng.integers(1, 4)), int(rng.integers(60, 500)),
+                              n_runs=int(rng.integers(0, 3)), repeats=(seed % 2 == 0), short=(seed % 2 == 1))
+    L = int(rng.integers(12, 25))
+    pats = synth.make_patterns(rng, ents, int(rng.integers(4, 30)), length=L, planted=0.7,
+                               minlen=(L - 4 if seed % 2 else None), indel_frac=0.5)
+    table = synth.table_for(ents)
+    raw = synth.stream(ents)
+    codes = synth.normalize(raw, table)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    for norm in (True, False):
+        text = O.Text(codes, table) if norm else O.Text(np.frombuffer(raw, dtype=np.uint8))
+        for sel, k, ind in CONFIGS:
+            ref = refrun.run_ref(ref_harness, codes if norm else raw, pats, table=table if norm else None,
+                                 sel=sel, k=k, indels=bool(ind), rc=True, minka=int(rng.integers(1, 50)))
+            eng = O.pick_engine(text, allp, k, bool(ind)) if sel == 0 else sel
+            got = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=bool(ind)))
+            assert got == ref, (seed, norm, sel, k, ind)
