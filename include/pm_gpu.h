@@ -1,0 +1,156 @@
+/* include/pm_gpu.h -- C ABI of the MI355X (gfx950) multi-pattern matcher.
+ *
+ * This is the drop-in boundary for the reference's PatternMatch plugin surface
+ * (reference: pattern_match.h:84-156) on the primer_match / pcr_match scan path.  One handle
+ * replaces one PatternMatch engine instance; every entry point names the reference interface it
+ * stands in for.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All functions return PM_OK (0) or a negative pm_status; pm_last_error() has the text.
+ * A handle is owned by one host thread (the reference is single-threaded).
+ *
+ * Data flow:  pm_create -> pm_add_pattern xN -> pm_init[_device] -> pm_scan ... -> pm_destroy
+ * Multi-GPU:  each rank pm_scan_candidates() on its shard of the stream, candidate records are
+ *             gathered (RCCL), one rank pm_finalize()s them in stream order.
+ */
+#ifndef PM_GPU_H
+#define PM_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+
+typedef struct pm_handle pm_handle;
+
+/* One hit, as the reference pushes it into pattern_hit_vector (pattern_match.h:82):
+ *   end = key  = stream index after the last matched char (cp.pos() at emission),
+ *   pid        = pattern_list_element::id() of value.first,
+ *   k          = value.second (0 for exact engines, min level for shift_and_inexact, DP value
+ *                for the seed+verify wrappers).
+ * In *candidate* records (pm_scan_candidates) aux[] carries engine-private data; it is zero in
+ * final hits. */
+typedef struct {
+  int64_t  end;
+  uint32_t pid;
+  uint8_t  k;
+  uint8_t  aux[3];
+} pm_hit;
+
+typedef enum {
+  PM_OK = 0,
+  PM_E_INVALID = -1,       /* bad argument / call order */
+  PM_E_UNSUPPORTED = -2,   /* valid in the reference, not implemented by this engine (message says what) */
+  PM_E_NOMEM = -3,
+  PM_E_HIP = -4,           /* HIP runtime error (no device, launch failure, ...) */
+  PM_E_OVERFLOW = -5,      /* candidate buffer too small; *n_out holds the required count */
+  PM_E_FATAL = -6          /* the reference would timestamp()+exit(1) here (e.g. select.cc:87-90) */
+} pm_status;
+
+/* Which reference engine's hit set to reproduce: the reference's own -N numbers
+ * (select.cc:197-265).  PM_SEM_AUTO applies pick_pattern_index's automatic choice
+ * (select.cc:101-141, NOPRIMEGEN build) to the patterns added. */
+typedef enum {
+  PM_SEM_AUTO = 0,
+  PM_SEM_KEYWORD_TREE = 2,      /* keyword_tree<...>::find_patterns (keyword_tree.t:427); -N 1,2,3 */
+  PM_SEM_SHIFT_AND = 4,         /* shift_and::find_patterns (shift_and.cc:208) */
+  PM_SEM_FILTER_BITVEC = 5,     /* filter_bitvec::find_patterns (filter_bitvec.cc:73) */
+  PM_SEM_EXACT_BASES = 8,       /* exact_bases::find_patterns (exact_bases.cc:69); -N 7..10 */
+  PM_SEM_EXACT_HALVES = 12,     /* exact_halves::find_patterns (exact_halves.cc:120); -N 11..14 */
+  PM_SEM_SHIFT_AND_INEXACT = 100 /* bare shift_and_inexact::find_patterns (shift_and_inexact.cc:249) */
+} pm_semantics;
+
+/* Which kernel family computes it (the "-N 16 / -N 17" of INTEGRATION.md). */
+typedef enum {
+  PM_KERNEL_AUTO = 0,
+  PM_KERNEL_BITPAR = 16,   /* bit-parallel Shift-And / Wu-Manber rows, any alphabet with <= 4 pattern codes */
+  PM_KERNEL_SEED = 17      /* 2-bit packed k-mer seeds (LDS filter) + verify; A,C,G,T patterns <= 32 nt */
+} pm_kernel;
+
+/* Replaces the constructor arguments of the reference engines as pick_pattern_index passes them
+ * (select.cc:19-30): nmismatch, indels, wildcard, textn, eos.  dna_mut is not supported. */
+typedef struct {
+  int32_t abi_version;     /* PM_ABI_VERSION */
+  int32_t semantics;       /* pm_semantics */
+  int32_t kernel;          /* pm_kernel */
+  int32_t k;               /* -k / -K value */
+  int32_t indels;          /* 1 = -k (edits), 0 = -K (substitutions only) */
+  int32_t wildcards;       /* -w/-W: must be 0 (PM_E_UNSUPPORTED otherwise) */
+  int32_t text_n;
+  int32_t eos;             /* raw end-of-sequence char, '\n' in the CLIs */
+  int32_t device;          /* HIP device ordinal */
+  int32_t reserved[7];
+} pm_config;
+
+/* new engine (reference: `new shift_and(...)` etc. in select.cc:197-265). */
+int pm_create(const pm_config *cfg, pm_handle **out);
+
+/* PatternMatch::add_pattern (pattern_match.h:116): pattern text, caller's id (CLIs use 1..N1,
+ * primer_match.cc:1105-1107), exact_start_bases / exact_end_bases. */
+int pm_add_pattern(pm_handle *h, const char *pat, size_t len, uint64_t id, int32_t esb, int32_t eeb);
+
+/* PatternMatch::init(CharacterProducer&) (pattern_match.h:130) for a host-resident stream:
+ * `text` = the bytes getnch() would return (c_str() of the mmap, char_io.h:167-169), n bytes;
+ * `table` = cp.ch(0..size-1) (the .tbl of a Normalized<> stream, char_io.t:216-246) or NULL for
+ * a raw stream (size 256, identity).  The bytes are copied to HBM; `text` must stay valid until
+ * pm_destroy (the verify stage reads windows from it). */
+int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8_t *table, int32_t table_len);
+
+/* Same, for a stream that is already resident in HBM (borrowed; 4-byte aligned).  `hip_stream`
+ * is a hipStream_t (NULL = default stream) on which all work of this handle is enqueued. */
+int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *table, int32_t table_len,
+                   void *hip_stream);
+
+/* PatternMatch::find_patterns (pattern_match.h:131) over the stream range [begin,end):
+ * appends to out[0..cap) every final hit with begin < hit.end <= end whose cluster/dedup fate is
+ * decided (filter_bitvec.cc:118-121 defers the rest to the next call), sorted by (end,pid).
+ * Ranges must be consecutive and increasing between pm_reset()s; end == n flushes everything.
+ * *more = 1 when out was too small: call again with begin == end to drain. */
+int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more);
+
+/* Device stage only, position-independent (what shards across GPUs): candidate records for
+ * begin < end_pos <= end.  Records stay in HBM (pm_candidates_device) and are copied to `out`
+ * when it is not NULL.  PM_E_OVERFLOW if more than the internal capacity (pm_set_capacity). */
+int pm_scan_candidates(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out);
+
+/* Asynchronous form for benchmarking and overlap: enqueue the scan on the handle's stream and
+ * return; pm_scan_wait() synchronises and reports the count. */
+int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end);
+int pm_scan_wait(pm_handle *h, size_t *n_out);
+
+/* HBM address of the records of the last pm_scan_candidates (for an RCCL gather) */
+int pm_candidates_device(pm_handle *h, void **d_records, size_t *n);
+int pm_set_capacity(pm_handle *h, size_t max_candidates);
+
+/* Host stage: cluster / dedup / verify candidate records that arrive in any order within a
+ * batch but batch-wise in increasing stream order (filter_bitvec.cc:88-177,
+ * exact_halves.cc:140-190).  `last` != 0 flushes deferred clusters.  Needs the text: either the
+ * host pointer given to pm_init or, for pm_init_device, windows fetched from HBM. */
+int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int last,
+                pm_hit *out, size_t cap, size_t *n_out);
+
+/* PatternMatch::reset (pattern_match.h:134): forget scan state, keep patterns and text. */
+int pm_reset(pm_handle *h);
+void pm_destroy(pm_handle *h);
+
+/* Introspection */
+const char *pm_last_error(const pm_handle *h);        /* NULL handle: error of the last pm_create */
+int pm_selected_semantics(const pm_handle *h);        /* resolved pm_semantics after pm_init */
+int pm_selected_kernel(const pm_handle *h);
+/* name of the dominant scan kernel and its launch geometry, for profiles */
+int pm_describe(const pm_handle *h, char *buf, size_t buflen);
+
+/* Timing of the scan kernels of the last pm_scan_candidates[_async], measured with HIP events on
+ * the handle's stream: milliseconds and number of launches. */
+int pm_last_kernel_time(pm_handle *h, float *ms, int *launches);
+
+/* pick_pattern_index's automatic choice (select.cc:101-141) without a handle. */
+int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized, int32_t k, int32_t wildcards,
+                      int32_t npat, const int32_t *patlen, const int32_t *esb, const int32_t *eeb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

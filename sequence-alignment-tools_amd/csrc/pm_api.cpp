@@ -1,0 +1,608 @@
+// pm_api.cpp -- the C ABI of include/pm_gpu.h: handle life cycle, engine selection, the device
+// scan stage and the host verify/cluster stage.
+//
+// Split of work (DESIGN.md "stages"):
+//   device  : scan kernels (pm_bitpar.hip / pm_seed.hip) turn the stream into sparse candidate
+//             records -- a pure function of (stream range, patterns), so it shards by position;
+//   host    : the order-dependent, sparse part of the reference wrappers -- filter_bitvec's
+//             clustering + one verify per cluster (filter_bitvec.cc:88-177), exact_halves'
+//             seed extension + per-pattern dedup (exact_halves.cc:140-190), exact_bases
+//             (exact_bases.cc:92-121) -- in stream order over the gathered records.
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "pm_internal.h"
+
+using namespace pm;
+
+namespace pm {
+void Alphabet::set_raw() {
+  size = 256;
+  for (int i = 0; i < 256; ++i) { ch[i] = (uint8_t)i; nch[i] = i; }
+}
+void Alphabet::set_table(const uint8_t *table, int len) {      // char_io.t:222-236
+  size = len;
+  for (int i = 0; i < 256; ++i) { ch[i] = 0; nch[i] = -1; }
+  for (int i = 0; i < len; ++i) { ch[i] = table[i]; nch[table[i]] = i; }
+}
+}  // namespace pm
+
+struct pm_handle {
+  pm_config cfg{};
+  std::vector<Pattern> pats;
+  Alphabet alpha;
+  int eos_code = -1;
+  int sem = 0, kern = 0;
+  bool inited = false;
+
+  const uint8_t *h_text = nullptr;
+  const uint8_t *d_text = nullptr;
+  bool own_d_text = false;
+  int64_t n = 0;
+  hipStream_t stream = nullptr;
+
+  // device stage
+  std::vector<Pattern> inner;
+  std::vector<uint32_t> inner_ids;
+  BitparDevice bp;
+  int scan_k = 0;
+  bool scan_indels = false;
+  pm_hit *d_cands = nullptr;
+  unsigned long long *d_counter = nullptr;
+  unsigned long long *h_counter = nullptr;     // pinned
+  size_t cap = 0;
+  size_t last_count = 0;
+  bool scan_pending = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  int last_launches = 0;
+  ScanGeometry geo{};
+
+  // host stage state
+  std::vector<pm_hit> carry;          // filter_bitvec: candidates whose cluster is not complete yet
+  std::vector<int64_t> lasthit;       // exact_halves: last kept end per pattern (exact_halves.cc:163)
+  std::vector<pm_hit> ready;          // final hits not yet handed out by pm_scan
+  size_t ready_pos = 0;
+  int64_t next_begin = 0;
+  AlignScratch scratch;
+  // window staging (verify stage)
+  std::vector<uint8_t> winbuf;
+  int64_t *d_wstart = nullptr; int32_t *d_wlen = nullptr; int64_t *d_woff = nullptr; uint8_t *d_wout = nullptr;
+  size_t d_wcap = 0, d_woutcap = 0;
+
+  std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(pm_handle *h, int code, const std::string &msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+static int hipfail(pm_handle *h, hipError_t e, const char *what) {
+  return fail(h, PM_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hipfail((h), e_, #expr); } while (0)
+
+// ---- pick_pattern_index, automatic branch (reference select.cc:31-141, NOPRIMEGEN, -x 0) -----
+extern "C" int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized, int32_t k, int32_t wildcards,
+                                 int32_t npat, const int32_t *patlen, const int32_t *esb, const int32_t *eeb) {
+  long min_exact = INT_MAX, at_least_half = 0, excess = 0, min_inexact = INT_MAX, min_len = INT_MAX;
+  for (int i = 0; i < npat; ++i) {
+    const int a = esb ? esb[i] : 0, b = eeb ? eeb[i] : 0;
+    const int c = a >= b ? a : b;                                  // the larger exact block decides
+    min_exact = std::min<long>(min_exact, c);
+    excess += c - patlen[i] / 2;
+    at_least_half += (c - patlen[i] / 2) >= 0;
+    min_inexact = std::min<long>(min_inexact, patlen[i] - c);
+    min_len = std::min<long>(min_len, patlen[i]);
+  }
+  min_inexact = std::min(min_inexact, min_len);
+  if (k > 0 && k >= min_inexact) return PM_E_FATAL;                // select.cc:87-90
+  int exact_engine;                                                // select.cc:101-115
+  if (wildcards) exact_engine = 4;
+  else if (alphabet_size < 255) exact_engine = acgt_normalized ? 2 : 3;
+  else exact_engine = 3;
+  if (k == 0) return exact_engine == 4 ? PM_SEM_SHIFT_AND : PM_SEM_KEYWORD_TREE;
+  const bool long_enough = (min_len >= 12 && alphabet_size < 10) || (min_len >= 8 && alphabet_size >= 10);
+  if (k == 1 && long_enough && (at_least_half <= 0 || excess <= 0)) return PM_SEM_EXACT_HALVES;   // :121-126
+  if (min_exact >= 6) return PM_SEM_EXACT_BASES;                   // :131-133
+  return PM_SEM_FILTER_BITVEC;                                     // :137-139
+}
+
+extern "C" int pm_create(const pm_config *cfg, pm_handle **out) {
+  if (!cfg || !out) return fail(nullptr, PM_E_INVALID, "pm_create: null argument");
+  if (cfg->abi_version != PM_ABI_VERSION) return fail(nullptr, PM_E_INVALID, "pm_create: ABI version mismatch");
+  if (cfg->wildcards) return fail(nullptr, PM_E_UNSUPPORTED, "IUPAC wildcard matching (-w/-W) is not implemented yet");
+  if (cfg->k < 0) return fail(nullptr, PM_E_INVALID, "pm_create: negative k");
+  pm_handle *h = new (std::nothrow) pm_handle();
+  if (!h) return fail(nullptr, PM_E_NOMEM, "out of memory");
+  h->cfg = *cfg;
+  h->alpha.set_raw();
+  *out = h;
+  return PM_OK;
+}
+
+extern "C" int pm_add_pattern(pm_handle *h, const char *pat, size_t len, uint64_t id, int32_t esb, int32_t eeb) {
+  if (!h || !pat) return PM_E_INVALID;
+  if (h->inited) return fail(h, PM_E_INVALID, "pm_add_pattern after pm_init");
+  if (id == 0) id = h->pats.size() + 1;                            // pattern_match.h:92-94
+  if (id > 0xffffffffull) return fail(h, PM_E_UNSUPPORTED, "pattern ids above 2^32-1");
+  h->pats.push_back(Pattern{std::string(pat, len), id, esb, eeb});
+  return PM_OK;
+}
+
+static void free_device(pm_handle *h) {
+  bitpar_free(&h->bp);
+  if (h->d_cands) (void)hipFree(h->d_cands);
+  if (h->d_counter) (void)hipFree(h->d_counter);
+  if (h->h_counter) (void)hipHostFree(h->h_counter);
+  if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->d_wstart) (void)hipFree(h->d_wstart);
+  if (h->d_wlen) (void)hipFree(h->d_wlen);
+  if (h->d_woff) (void)hipFree(h->d_woff);
+  if (h->d_wout) (void)hipFree(h->d_wout);
+  h->d_cands = nullptr; h->d_counter = nullptr; h->h_counter = nullptr; h->d_text = nullptr;
+  h->ev0 = h->ev1 = nullptr; h->d_wstart = nullptr; h->d_wlen = nullptr; h->d_woff = nullptr; h->d_wout = nullptr;
+  h->d_wcap = h->d_woutcap = 0;
+}
+
+static int ensure_capacity(pm_handle *h, size_t cap, bool exact = false) {
+  if (h->d_cands && (exact ? h->cap == cap : h->cap >= cap)) return PM_OK;
+  if (h->d_cands) (void)hipFree(h->d_cands);
+  h->d_cands = nullptr;
+  HIP_TRY(h, hipMalloc((void **)&h->d_cands, cap * sizeof(pm_hit)));
+  h->cap = cap;
+  return PM_OK;
+}
+
+// Decide the reference engine to reproduce and derive the inner (device) pattern set from it.
+static int resolve(pm_handle *h) {
+  const int np = (int)h->pats.size();
+  std::vector<int32_t> len(np), esb(np), eeb(np);
+  for (int i = 0; i < np; ++i) { len[i] = (int)h->pats[i].s.size(); esb[i] = h->pats[i].esb; eeb[i] = h->pats[i].eeb; }
+  const Alphabet &A = h->alpha;
+  const bool acgt = A.nch['A'] == 0 && A.nch['C'] == 1 && A.nch['G'] == 2 && A.nch['T'] == 3;
+  int sem = h->cfg.semantics;
+  // the "edits >= inexact bases" check runs for every -N (select.cc:87-90)
+  const int autosem = pm_pick_semantics(A.size, acgt, h->cfg.k, h->cfg.wildcards, np, len.data(), esb.data(), eeb.data());
+  if (autosem == PM_E_FATAL)
+    return fail(h, PM_E_FATAL, "Fatal error: Number of edits >= Minimum number of inexact bases");
+  if (sem == PM_SEM_AUTO) sem = autosem;
+  switch (sem) {
+    case 1: case 2: case 3: sem = PM_SEM_KEYWORD_TREE; break;
+    case 4: break;
+    case 5: break;
+    case 7: case 8: case 9: case 10: sem = PM_SEM_EXACT_BASES; break;
+    case 11: case 12: case 13: case 14: sem = PM_SEM_EXACT_HALVES; break;
+    case PM_SEM_SHIFT_AND_INEXACT: break;
+    default: return fail(h, PM_E_INVALID, "unknown semantics selector");
+  }
+  h->sem = sem;
+  h->inner.clear(); h->inner_ids.clear();
+  h->scan_k = 0; h->scan_indels = false;
+  switch (sem) {
+    case PM_SEM_KEYWORD_TREE: case PM_SEM_SHIFT_AND:
+      for (const Pattern &p : h->pats) { h->inner.push_back(p); h->inner_ids.push_back((uint32_t)p.id); }
+      break;
+    case PM_SEM_SHIFT_AND_INEXACT:
+      for (const Pattern &p : h->pats) { h->inner.push_back(p); h->inner_ids.push_back((uint32_t)p.id); }
+      h->scan_k = h->cfg.k; h->scan_indels = h->cfg.indels != 0;
+      break;
+    case PM_SEM_FILTER_BITVEC:                                      // filter_bitvec.cc:185-196
+      for (int i = 0; i < np; ++i) { h->inner.push_back(h->pats[i]); h->inner_ids.push_back((uint32_t)(i + 1)); }
+      h->scan_k = h->cfg.k; h->scan_indels = h->cfg.indels != 0;
+      break;
+    case PM_SEM_EXACT_HALVES:                                       // exact_halves.cc:199-224
+      for (int i = 0; i < np; ++i) {
+        const std::string &s = h->pats[i].s;
+        const size_t l1 = s.size() / 2;
+        if (l1 == 0) return fail(h, PM_E_UNSUPPORTED, "exact_halves needs patterns of length >= 2");
+        h->inner.push_back(Pattern{s.substr(0, l1), 0, 0, 0}); h->inner_ids.push_back((uint32_t)(2 * i + 1));
+        h->inner.push_back(Pattern{s.substr(l1), 0, 0, 0});    h->inner_ids.push_back((uint32_t)(2 * i + 2));
+      }
+      h->lasthit.assign(np + 1, 0);
+      break;
+    case PM_SEM_EXACT_BASES:                                        // exact_bases.cc:131-160
+      for (int i = 0; i < np; ++i) {
+        const Pattern &p = h->pats[i];
+        const int L = (int)p.s.size();
+        const int cut = p.esb >= p.eeb ? p.esb : p.eeb;
+        if (cut <= 0 || cut > L) return fail(h, PM_E_UNSUPPORTED, "exact_bases needs 0 < exact bases <= pattern length");
+        h->inner.push_back(Pattern{p.esb >= p.eeb ? p.s.substr(0, p.esb) : p.s.substr(L - p.eeb), 0, 0, 0});
+        h->inner_ids.push_back((uint32_t)(i + 1));
+      }
+      break;
+  }
+  int kern = h->cfg.kernel;
+  if (kern == PM_KERNEL_AUTO) kern = PM_KERNEL_BITPAR;
+  if (kern != PM_KERNEL_BITPAR) return fail(h, PM_E_UNSUPPORTED, "seed kernel family is not available in this build");
+  h->kern = kern;
+  return PM_OK;
+}
+
+static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
+  if (table) {
+    if (table_len <= 0 || table_len > 256) return fail(h, PM_E_INVALID, "bad alphabet table length");
+    h->alpha.set_table(table, table_len);
+  } else h->alpha.set_raw();
+  h->eos_code = h->alpha.nch[(uint8_t)h->cfg.eos];                  // shift_and_inexact.cc:131
+  int rc = resolve(h);
+  if (rc) return rc;
+  BitparTables tabs;
+  std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs);
+  if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine: " + msg);
+  HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
+  if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, sizeof(unsigned long long)));
+  if (!h->h_counter) HIP_TRY(h, hipHostMalloc((void **)&h->h_counter, sizeof(unsigned long long), hipHostMallocDefault));
+  if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
+  if (!h->ev1) HIP_TRY(h, hipEventCreate(&h->ev1));
+  if (!h->d_cands) { rc = ensure_capacity(h, (size_t)1 << 20); if (rc) return rc; }
+  h->inited = true;
+  return pm_reset(h);
+}
+
+extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8_t *table, int32_t table_len) {
+  if (!h || (!text && n > 0) || n < 0) return fail(h, PM_E_INVALID, "pm_init: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (h->own_d_text && h->d_text) { (void)hipFree((void *)h->d_text); h->d_text = nullptr; }
+  void *d = nullptr;
+  HIP_TRY(h, hipMalloc(&d, (size_t)(n > 0 ? n : 1) + 16));
+  if (n > 0) HIP_TRY(h, hipMemcpy(d, text, (size_t)n, hipMemcpyHostToDevice));
+  h->d_text = (const uint8_t *)d; h->own_d_text = true; h->h_text = text; h->n = n; h->stream = nullptr;
+  return init_common(h, table, table_len);
+}
+
+extern "C" int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *table, int32_t table_len,
+                              void *hip_stream) {
+  if (!h || (!d_text && n > 0) || n < 0) return fail(h, PM_E_INVALID, "pm_init_device: bad arguments");
+  if (((uintptr_t)d_text) & 3) return fail(h, PM_E_INVALID, "pm_init_device: stream must be 4-byte aligned");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
+  h->d_text = (const uint8_t *)d_text; h->own_d_text = false; h->h_text = nullptr; h->n = n;
+  h->stream = (hipStream_t)hip_stream;
+  return init_common(h, table, table_len);
+}
+
+extern "C" int pm_set_capacity(pm_handle *h, size_t max_candidates) {
+  if (!h || max_candidates == 0) return PM_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return ensure_capacity(h, max_candidates, true);
+}
+
+extern "C" int pm_reset(pm_handle *h) {
+  if (!h) return PM_E_INVALID;
+  h->carry.clear(); h->ready.clear(); h->ready_pos = 0; h->next_begin = 0;
+  std::fill(h->lasthit.begin(), h->lasthit.end(), 0);
+  h->last_count = 0; h->scan_pending = false;
+  return PM_OK;
+}
+
+extern "C" void pm_destroy(pm_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  free_device(h);
+  delete h;
+}
+
+extern "C" const char *pm_last_error(const pm_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+extern "C" int pm_selected_semantics(const pm_handle *h) { return h && h->inited ? h->sem : PM_E_INVALID; }
+extern "C" int pm_selected_kernel(const pm_handle *h) { return h && h->inited ? h->kern : PM_E_INVALID; }
+
+extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
+  if (!h || !buf || !h->inited) return PM_E_INVALID;
+  snprintf(buf, buflen, "kernel=%s tiles=%d lanes_per_tile=64 words_per_lane=%d seg_len=%lld nseg=%d grid=%d block=%d",
+           bitpar_kernel_name(h->scan_k, h->scan_indels), h->bp.ntiles, BP_WPL, (long long)h->geo.seg_len, h->geo.nseg,
+           h->geo.blocks, h->geo.threads);
+  return PM_OK;
+}
+
+// ---- device stage ------------------------------------------------------------------------------
+extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end) {
+  if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_scan_candidates: handle not initialised");
+  if (begin < 0 || end < begin) return fail(h, PM_E_INVALID, "pm_scan_candidates: bad range");
+  if (end > h->n) end = h->n;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  h->last_launches = 1;
+  h->scan_pending = true;
+  return PM_OK;
+}
+
+extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
+  if (!h || !h->scan_pending) return fail(h, PM_E_INVALID, "pm_scan_wait: no scan in flight");
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->scan_pending = false;
+  (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
+  const size_t cnt = (size_t)*h->h_counter;
+  if (n_out) *n_out = cnt;
+  if (cnt > h->cap) { h->last_count = 0; return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
+  h->last_count = cnt;
+  return PM_OK;
+}
+
+extern "C" int pm_scan_candidates(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out) {
+  int rc = pm_scan_candidates_async(h, begin, end);
+  if (rc) return rc;
+  size_t cnt = 0;
+  rc = pm_scan_wait(h, &cnt);
+  if (n_out) *n_out = cnt;
+  if (rc) return rc;
+  if (out) {
+    if (cnt > cap) return fail(h, PM_E_OVERFLOW, "pm_scan_candidates: out buffer too small");
+    if (cnt) HIP_TRY(h, hipMemcpy(out, h->d_cands, cnt * sizeof(pm_hit), hipMemcpyDeviceToHost));
+  }
+  return PM_OK;
+}
+
+extern "C" int pm_candidates_device(pm_handle *h, void **d_records, size_t *n) {
+  if (!h || !h->inited) return PM_E_INVALID;
+  if (d_records) *d_records = h->d_cands;
+  if (n) *n = h->last_count;
+  return PM_OK;
+}
+
+extern "C" int pm_last_kernel_time(pm_handle *h, float *ms, int *launches) {
+  if (!h) return PM_E_INVALID;
+  if (ms) *ms = h->last_ms;
+  if (launches) *launches = h->last_launches;
+  return PM_OK;
+}
+
+// ---- host stage --------------------------------------------------------------------------------
+namespace {
+
+struct Window { int64_t start; int32_t len; int64_t off; };
+
+// Raw characters (cp.getch()) of a batch of stream windows, from the host copy of the stream
+// when there is one, else gathered from HBM by one kernel + one copy.  Bytes outside [0,n) read
+// as code 0, like the reference's unchecked mmap reads of the zero-padded last page.
+int fetch_windows(pm_handle *h, std::vector<Window> &wins) {
+  int64_t total = 0;
+  for (Window &w : wins) { w.off = total; total += w.len; }
+  h->winbuf.resize((size_t)total + 1);
+  if (wins.empty()) return PM_OK;
+  if (h->h_text) {
+    for (const Window &w : wins)
+      for (int i = 0; i < w.len; ++i) {
+        const int64_t p = w.start + i;
+        h->winbuf[w.off + i] = (p >= 0 && p < h->n) ? h->h_text[p] : 0;
+      }
+  } else {
+    const size_t cnt = wins.size();
+    if (h->d_wcap < cnt) {
+      if (h->d_wstart) { (void)hipFree(h->d_wstart); (void)hipFree(h->d_wlen); (void)hipFree(h->d_woff); }
+      h->d_wcap = cnt * 2;
+      HIP_TRY(h, hipMalloc((void **)&h->d_wstart, h->d_wcap * 8));
+      HIP_TRY(h, hipMalloc((void **)&h->d_wlen, h->d_wcap * 4));
+      HIP_TRY(h, hipMalloc((void **)&h->d_woff, h->d_wcap * 8));
+    }
+    if (h->d_woutcap < (size_t)total) {
+      if (h->d_wout) (void)hipFree(h->d_wout);
+      h->d_woutcap = (size_t)total * 2;
+      HIP_TRY(h, hipMalloc((void **)&h->d_wout, h->d_woutcap));
+    }
+    std::vector<int64_t> st(cnt), of(cnt); std::vector<int32_t> ln(cnt);
+    for (size_t i = 0; i < cnt; ++i) { st[i] = wins[i].start; ln[i] = wins[i].len; of[i] = wins[i].off; }
+    HIP_TRY(h, hipMemcpyAsync(h->d_wstart, st.data(), cnt * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_wlen, ln.data(), cnt * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_woff, of.data(), cnt * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, gather_windows(h->d_text, h->n, h->d_wstart, h->d_wlen, h->d_woff, (int)cnt, h->d_wout, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->winbuf.data(), h->d_wout, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  for (int64_t i = 0; i < total; ++i) h->winbuf[i] = h->alpha.ch[h->winbuf[i]];
+  return PM_OK;
+}
+
+bool by_end_pid(const pm_hit &a, const pm_hit &b) {
+  if (a.end != b.end) return a.end < b.end;
+  if (a.pid != b.pid) return a.pid < b.pid;
+  return a.k < b.k;
+}
+
+pm_hit make_hit(int64_t end, uint64_t pid, int k) {
+  pm_hit x; x.end = end; x.pid = (uint32_t)pid; x.k = (uint8_t)k; x.aux[0] = x.aux[1] = x.aux[2] = 0;
+  return x;
+}
+
+// filter_bitvec::find_patterns (filter_bitvec.cc:88-177) over carried + new candidates.
+int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
+                           std::vector<pm_hit> &outv) {
+  std::vector<pm_hit> &l = h->carry;
+  l.insert(l.end(), cands, cands + n);
+  std::stable_sort(l.begin(), l.end(), by_end_pid);                 // l.normalize() (:92)
+  const int k = h->cfg.k, win = 2 * k + 1;
+  const bool indels = h->cfg.indels != 0;
+  struct Cluster { int64_t first, last; uint32_t pid; int best_lvl; int64_t best_end; };
+  std::vector<Cluster> clusters;
+  std::vector<char> used(l.size(), 0);
+  size_t stop = l.size();
+  for (size_t i = 0; i < l.size(); ++i) {
+    if (used[i]) continue;
+    Cluster c{l[i].end, l[i].end, l[i].pid, l[i].k, l[i].end};
+    std::vector<size_t> members{i};
+    for (size_t j = i + 1; j < l.size() && (used[j] || l[j].end <= c.last + win); ++j) {   // :103-116
+      if (used[j] || l[j].pid != c.pid) continue;
+      c.last = l[j].end;
+      if (l[j].k < c.best_lvl) { c.best_lvl = l[j].k; c.best_end = l[j].end; }
+      members.push_back(j);
+    }
+    if (!last && scanned_to < c.last + win) { stop = i; break; }    // :118-121: cluster may still grow
+    for (size_t m : members) used[m] = 1;
+    clusters.push_back(c);
+  }
+  // Verify.  Substitution-only search without exact-base constraints needs no text: the DP
+  // (pattern_alignment.cc, b = 0) walks diagonals only, so the cluster's value is the smallest
+  // Hamming distance among its windows -- which is the smallest candidate level, windows that
+  // are not candidates having distance > k -- and the column rule (:461-475) keeps the
+  // left-most such window.
+  std::vector<Window> wins;
+  std::vector<size_t> need_dp;
+  for (size_t ci = 0; ci < clusters.size(); ++ci) {
+    const Cluster &c = clusters[ci];
+    const Pattern &p = h->pats[c.pid - 1];
+    if (!indels && p.esb == 0 && p.eeb == 0) {
+      outv.push_back(make_hit(c.best_end, p.id, c.best_lvl));
+    } else {
+      const int L = (int)p.s.size();
+      int64_t ws = 0;
+      if (c.first > (int64_t)L + k) ws = c.first - L - k;           // pattern_alignment.cc:137-139
+      wins.push_back(Window{ws, (int32_t)(c.last - ws), 0});
+      need_dp.push_back(ci);
+    }
+  }
+  int rc = fetch_windows(h, wins);
+  if (rc) return rc;
+  AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
+  for (size_t wi = 0; wi < need_dp.size(); ++wi) {
+    const Cluster &c = clusters[need_dp[wi]];
+    const Pattern &p = h->pats[c.pid - 1];
+    AlignResult r = editdist_align(h->winbuf.data() + wins[wi].off, wins[wi].start, c.first, c.last,
+                                   p.s.data(), (int)p.s.size(), p.esb, p.eeb, prm, h->scratch);
+    if (r.ok) outv.push_back(make_hit(r.end, p.id, r.value));       // :135
+  }
+  // keep what was not consumed (:137-170)
+  std::vector<pm_hit> rest;
+  for (size_t i = 0; i < l.size(); ++i) if (!used[i]) rest.push_back(l[i]);
+  (void)stop;
+  l.swap(rest);
+  return PM_OK;
+}
+
+bool seed_order(const pm_hit &a, const pm_hit &b) {                  // exact_halves.cc:114-118
+  if (a.end != b.end) return a.end < b.end;
+  return a.pid > b.pid;
+}
+
+// exact_halves::find_patterns (exact_halves.cc:140-190) / exact_bases (exact_bases.cc:92-121)
+int finalize_seeds(pm_handle *h, const pm_hit *cands, size_t n, bool halves, std::vector<pm_hit> &outv) {
+  std::vector<pm_hit> seeds(cands, cands + n);
+  if (halves) std::sort(seeds.begin(), seeds.end(), seed_order);
+  else std::sort(seeds.begin(), seeds.end(), by_end_pid);
+  const int k = h->cfg.k;
+  const bool indels = h->cfg.indels != 0;
+  struct Job { int pat; bool left; int len1, len2; };
+  std::vector<Job> jobs(seeds.size());
+  std::vector<Window> wins(seeds.size());
+  for (size_t i = 0; i < seeds.size(); ++i) {
+    const uint32_t hid = seeds[i].pid;
+    Job j;
+    if (halves) {
+      j.pat = (int)((hid - 1) / 2);
+      const int L = (int)h->pats[j.pat].s.size();
+      j.len1 = L / 2; j.len2 = L - j.len1; j.left = (hid % 2) == 1;
+    } else {
+      j.pat = (int)hid - 1;
+      const Pattern &p = h->pats[j.pat];
+      const int L = (int)p.s.size();
+      j.left = p.esb >= p.eeb;
+      j.len1 = j.left ? p.esb : L - p.eeb; j.len2 = L - j.len1;
+    }
+    jobs[i] = j;
+    if (j.left) wins[i] = Window{seeds[i].end, j.len2 + k, 0};                       // primer_alignment.cc:573-574
+    else {
+      int64_t ws = 0;
+      const int plen = j.len1 + j.len2 + k;
+      if (seeds[i].end > (int64_t)plen) ws = seeds[i].end - plen;                      // :657-662
+      wins[i] = Window{ws, (int32_t)std::max<int64_t>(0, seeds[i].end - j.len2 - ws), 0};
+    }
+  }
+  int rc = fetch_windows(h, wins);
+  if (rc) return rc;
+  AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
+  for (size_t i = 0; i < seeds.size(); ++i) {
+    const Job &j = jobs[i];
+    const Pattern &p = h->pats[j.pat];
+    int64_t end = 0; int val = 0; bool ok;
+    if (j.left) ok = lmatch_extend(h->winbuf.data() + wins[i].off, seeds[i].end, j.len1, p.s.data() + j.len1, j.len2,
+                                   p.esb, p.eeb, prm, h->scratch, &end, &val);
+    else ok = rmatch_extend(h->winbuf.data() + wins[i].off, wins[i].len, seeds[i].end, p.s.data(), j.len1, j.len2,
+                            p.esb, p.eeb, prm, h->scratch, &end, &val);
+    if (!ok) continue;
+    if (halves) {
+      if (end > h->lasthit[j.pat + 1] + (indels ? 2 * k : 0)) {      // exact_halves.cc:163,178
+        outv.push_back(make_hit(end, p.id, val));
+        h->lasthit[j.pat + 1] = end;
+      }
+    } else outv.push_back(make_hit(end, p.id, val));
+  }
+  return PM_OK;
+}
+
+}  // namespace
+
+static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
+                         std::vector<pm_hit> &outv) {
+  int rc = PM_OK;
+  switch (h->sem) {
+    case PM_SEM_KEYWORD_TREE: case PM_SEM_SHIFT_AND: case PM_SEM_SHIFT_AND_INEXACT:
+      outv.insert(outv.end(), cands, cands + n);
+      break;
+    case PM_SEM_FILTER_BITVEC: rc = finalize_filter_bitvec(h, cands, n, scanned_to, last, outv); break;
+    case PM_SEM_EXACT_HALVES: rc = finalize_seeds(h, cands, n, true, outv); break;
+    case PM_SEM_EXACT_BASES: rc = finalize_seeds(h, cands, n, false, outv); break;
+    default: return fail(h, PM_E_INVALID, "finalize: bad semantics");
+  }
+  return rc;
+}
+
+extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int last,
+                           pm_hit *out, size_t cap, size_t *n_out) {
+  if (!h || !h->inited || (!cands && n)) return fail(h, PM_E_INVALID, "pm_finalize: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::vector<pm_hit> outv;
+  int rc = finalize_into(h, cands, n, scanned_to, last != 0, outv);
+  if (rc) return rc;
+  std::sort(outv.begin(), outv.end(), by_end_pid);
+  if (n_out) *n_out = outv.size();
+  if (outv.size() > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize: out buffer too small");
+  if (!outv.empty()) memcpy(out, outv.data(), outv.size() * sizeof(pm_hit));
+  return PM_OK;
+}
+
+extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more) {
+  if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_scan: handle not initialised");
+  if (n_out) *n_out = 0;
+  if (more) *more = 0;
+  if (end > h->n) end = h->n;
+  if (end > begin) {
+    if (begin != h->next_begin) return fail(h, PM_E_INVALID, "pm_scan: ranges must be consecutive (pm_reset to restart)");
+    std::vector<pm_hit> cands;
+    size_t cnt = 0;
+    int rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
+    while (rc == PM_E_OVERFLOW && cnt > h->cap) {                     // grow and redo this range
+      rc = ensure_capacity(h, cnt + cnt / 4 + 1024);
+      if (rc) return rc;
+      rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
+    }
+    if (rc) return rc;
+    cands.resize(cnt);
+    if (cnt) HIP_TRY(h, hipMemcpy(cands.data(), h->d_cands, cnt * sizeof(pm_hit), hipMemcpyDeviceToHost));
+    std::vector<pm_hit> outv;
+    rc = finalize_into(h, cands.data(), cnt, end, end >= h->n, outv);
+    if (rc) return rc;
+    std::sort(outv.begin(), outv.end(), by_end_pid);
+    if (h->ready_pos == h->ready.size()) { h->ready.clear(); h->ready_pos = 0; }
+    h->ready.insert(h->ready.end(), outv.begin(), outv.end());
+    h->next_begin = end;
+  }
+  size_t avail = h->ready.size() - h->ready_pos;
+  size_t take = std::min(avail, cap);
+  if (take && out) memcpy(out, h->ready.data() + h->ready_pos, take * sizeof(pm_hit));
+  else take = out ? take : 0;
+  h->ready_pos += take;
+  if (n_out) *n_out = take;
+  if (more) *more = h->ready_pos < h->ready.size();
+  return PM_OK;
+}

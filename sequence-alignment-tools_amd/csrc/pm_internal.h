@@ -1,0 +1,75 @@
+// pm_internal.h -- shared declarations of the product path (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pm_gpu.h"
+#include "pm_align.h"
+
+namespace pm {
+
+struct Pattern {
+  std::string s;
+  uint64_t    id;
+  int         esb, eeb;
+};
+
+// The CharacterProducer facts an engine needs (reference char_io.h:18-71): ch(), nch(), size().
+struct Alphabet {
+  int     size = 256;
+  uint8_t ch[256];
+  int     nch[256];
+  void set_raw();
+  void set_table(const uint8_t *table, int len);
+};
+
+// ---- bit-parallel family (pm_bitpar.hip) -----------------------------------------------------
+constexpr int BP_WPL = 8;          // 32-bit words per lane: a lane holds a 256-bit pattern string
+constexpr int BP_NC = 4;           // distinct text codes the patterns may use (A,C,G,T)
+constexpr int BP_BLOCK = 256;      // text bytes per block step (64 lanes x 4 bytes)
+
+struct BitparTables {              // host-built, then uploaded
+  int ntiles = 0;                  // 64 lanes per tile
+  int k = 0;
+  int maxlen = 0;
+  int nclasses = 0;                // pattern codes in use (<= BP_NC)
+  uint8_t cmap[256];               // text code -> class: 0..BP_NC-1, BP_NC = other, BP_NC+1 = EOS
+  std::vector<uint32_t> U;         // [tile][cls][w][lane]
+  std::vector<uint32_t> S;         // [tile][w][lane]   first-char bits
+  std::vector<uint32_t> LAST;      // [tile][w][lane]   last-char bits
+  std::vector<uint32_t> INIT;      // [tile][l-1][w][lane]  row l start state (l = 1..k)
+  std::vector<uint32_t> lane_first;// [tile*64+lane] -> first index into pid_of for that lane
+  std::vector<uint32_t> pid_of;    // pattern id per packed pattern, in (tile,lane,bit) order
+};
+
+struct BitparDevice {
+  uint32_t *U = nullptr, *S = nullptr, *LAST = nullptr, *INIT = nullptr, *lane_first = nullptr, *pid_of = nullptr;
+  uint8_t  *cmap = nullptr;
+  int ntiles = 0, k = 0, maxlen = 0;
+  bool indels = false;
+};
+
+// Build the packed tables.  Returns "" or an error message (PM_E_UNSUPPORTED).
+std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
+                         const Alphabet &alpha, int k, int eos_code, BitparTables *out);
+hipError_t bitpar_upload(const BitparTables &t, bool indels, BitparDevice *d, hipStream_t st);
+void bitpar_free(BitparDevice *d);
+
+struct ScanGeometry { int64_t seg_len; int nseg; int blocks; int threads; };
+ScanGeometry bitpar_geometry(const BitparDevice &d, int64_t begin, int64_t end);
+
+// Enqueue the scan of stream range (begin,end] (hit end positions) on `st`.
+// out/counter are device pointers; counter must be zeroed by the caller (async memset).
+hipError_t bitpar_launch(const BitparDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
+                         pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
+                         ScanGeometry *geo_out);
+const char *bitpar_kernel_name(int k, bool indels);
+
+// ---- window gather (verify stage text access when the stream lives only in HBM) -------------
+hipError_t gather_windows(const uint8_t *d_text, int64_t n, const int64_t *d_starts, const int32_t *d_lens,
+                          const int64_t *d_offsets, int count, uint8_t *d_out, hipStream_t st);
+
+}  // namespace pm

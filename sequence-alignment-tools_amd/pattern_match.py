@@ -1,0 +1,265 @@
+"""ctypes binding of include/pm_gpu.h and a PatternMatch-shaped host class."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = None
+
+HIT_DTYPE = np.dtype([("end", "<i8"), ("pid", "<u4"), ("k", "u1"), ("aux", "u1", (3,))])
+
+SEM_AUTO, SEM_KEYWORD_TREE, SEM_SHIFT_AND, SEM_FILTER_BITVEC = 0, 2, 4, 5
+SEM_EXACT_BASES, SEM_EXACT_HALVES, SEM_SHIFT_AND_INEXACT = 8, 12, 100
+KERNEL_AUTO, KERNEL_BITPAR, KERNEL_SEED = 0, 16, 17
+PM_E_OVERFLOW = -5
+
+# every entry point include/pm_gpu.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_candidates",
+    "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
+    "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
+    "pm_last_kernel_time", "pm_pick_semantics",
+]
+
+
+class PmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pm_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("semantics", C.c_int32), ("kernel", C.c_int32), ("k", C.c_int32),
+                ("indels", C.c_int32), ("wildcards", C.c_int32), ("text_n", C.c_int32), ("eos", C.c_int32),
+                ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+def library_path():
+    return os.path.join(_CSRC, "libpm_gpu.so")
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", _CSRC])
+    return library_path()
+
+
+def load_library():
+    """Load csrc/libpm_gpu.so.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise PmError(-4, "HIP extension %s is not built (run __graft_entry__.build())" % path)
+        L = C.CDLL(path)
+        L.pm_last_error.restype = C.c_char_p
+        L.pm_last_error.argtypes = [C.c_void_p]
+        L.pm_destroy.restype = None
+        L.pm_destroy.argtypes = [C.c_void_p]
+        for name in ABI_SYMBOLS:
+            f = getattr(L, name)
+            if name not in ("pm_last_error", "pm_destroy"):
+                f.restype = C.c_int
+        L.pm_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+        L.pm_add_pattern.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_int32, C.c_int32]
+        L.pm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        L.pm_init_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+        L.pm_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.pm_scan_candidates.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.pm_scan_candidates_async.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.pm_scan_wait.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.pm_candidates_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.pm_set_capacity.argtypes = [C.c_void_p, C.c_size_t]
+        L.pm_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.pm_reset.argtypes = [C.c_void_p]
+        L.pm_selected_semantics.argtypes = [C.c_void_p]
+        L.pm_selected_kernel.argtypes = [C.c_void_p]
+        L.pm_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.pm_last_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.pm_pick_semantics.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def pick_semantics(alphabet_size, acgt_normalized, k, patterns, esb=None, eeb=None, wildcards=False):
+    """pick_pattern_index's automatic engine choice (reference select.cc:101-141)."""
+    L = load_library()
+    pl = np.array([len(p) for p in patterns], dtype=np.int32)
+    a = lambda x: None if x is None else np.ascontiguousarray(x, dtype=np.int32).ctypes.data_as(C.c_void_p)
+    return L.pm_pick_semantics(alphabet_size, int(acgt_normalized), k, int(wildcards), len(patterns),
+                               pl.ctypes.data_as(C.c_void_p), a(esb), a(eeb))
+
+
+def reverse_comp(p):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+    return "".join(comp.get(c, c) for c in reversed(p))
+
+
+def sorted_tuples(hits):
+    return sorted(zip(hits["end"].tolist(), hits["pid"].tolist(), hits["k"].tolist()))
+
+
+class PatternMatch:
+    """Host-side mirror of the reference's PatternMatch (pattern_match.h:84-156) over the GPU engine.
+
+    k / indels / eos follow pick_pattern_index's arguments (select.cc:19-30): indels=True is the
+    CLI's -k (edits), False is -K (substitutions only).  `semantics` forces a reference engine
+    (-N), SEM_AUTO reproduces the automatic choice; `kernel` picks the GPU kernel family.
+    """
+
+    def __init__(self, k=0, indels=True, eos="\n", semantics=SEM_AUTO, kernel=KERNEL_AUTO, device=0):
+        self._L = load_library()
+        cfg = _Config()
+        cfg.abi_version, cfg.semantics, cfg.kernel, cfg.k = 1, semantics, kernel, k
+        cfg.indels, cfg.wildcards, cfg.text_n = int(bool(indels)), 0, 0
+        cfg.eos = ord(eos) if isinstance(eos, str) else int(eos)
+        cfg.device = device
+        self._h = C.c_void_p()
+        rc = self._L.pm_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            raise PmError(rc, (self._L.pm_last_error(None) or b"").decode())
+        self._n = 0
+        self._pos = 0
+        self._keep = None
+
+    def _check(self, rc):
+        if rc:
+            raise PmError(rc, (self._L.pm_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- PatternMatch::add_pattern (pattern_match.h:116) --------------------------------------
+    def add_pattern(self, pat, id=0, exact_start_bases=0, exact_end_bases=0):
+        b = pat.encode() if isinstance(pat, str) else bytes(pat)
+        self._check(self._L.pm_add_pattern(self._h, b, len(b), id, exact_start_bases, exact_end_bases))
+        return id
+
+    # -- PatternMatch::init (pattern_match.h:130) -----------------------------------------------
+    def init(self, text, table=None):
+        """`text`: uint8 numpy array (host stream bytes as getnch() returns them).
+        `table`: cp.ch(0..size-1) for a normalized stream, None for a raw one."""
+        arr = np.ascontiguousarray(text, dtype=np.uint8)
+        self._keep = arr                      # pm_init borrows the host pointer
+        tb = None if table is None else (C.c_uint8 * len(table)).from_buffer_copy(bytes(table))
+        self._check(self._L.pm_init(self._h, arr.ctypes.data_as(C.c_void_p), arr.size, tb, 0 if table is None else len(table)))
+        self._n, self._pos = arr.size, 0
+
+    def init_device(self, data_ptr, n, table=None, stream=None, keepalive=None):
+        """Stream already resident in HBM (e.g. a torch uint8 tensor's data_ptr())."""
+        self._keep = keepalive
+        tb = None if table is None else (C.c_uint8 * len(table)).from_buffer_copy(bytes(table))
+        self._check(self._L.pm_init_device(self._h, C.c_void_p(data_ptr), n, tb, 0 if table is None else len(table),
+                                           C.c_void_p(stream or 0)))
+        self._n, self._pos = n, 0
+
+    # -- PatternMatch::find_patterns (pattern_match.h:131) -------------------------------------
+    def find_patterns(self, hits, minka=1, chunk=1 << 26):
+        """Scan on from the current stream position until >= minka hits were produced or the end
+        of the stream; appends (end, pid, k) tuples to `hits`; returns True if any were appended
+        (the reference's `more`).  pos() afterwards is the scanned-to position."""
+        got = 0
+        buf = np.zeros(1 << 16, dtype=HIT_DTYPE)
+        n_out, more = C.c_size_t(), C.c_int()
+        while True:
+            begin = self._pos
+            end = min(self._n, begin + chunk)
+            self._check(self._L.pm_scan(self._h, begin, end, buf.ctypes.data_as(C.c_void_p), buf.size,
+                                        C.byref(n_out), C.byref(more)))
+            self._pos = end
+            while True:
+                for i in range(n_out.value):
+                    hits.append((int(buf["end"][i]), int(buf["pid"][i]), int(buf["k"][i])))
+                got += n_out.value
+                if not more.value:
+                    break
+                self._check(self._L.pm_scan(self._h, end, end, buf.ctypes.data_as(C.c_void_p), buf.size,
+                                            C.byref(n_out), C.byref(more)))
+            if got >= minka or self._pos >= self._n:
+                return got > 0
+
+    def find_all(self, chunk=1 << 26):
+        """All hits over the whole stream as a structured array sorted by (end, pid)."""
+        self.reset()
+        hits = []
+        while self.find_patterns(hits, minka=1 << 62, chunk=chunk):
+            if self._pos >= self._n:
+                break
+        out = np.zeros(len(hits), dtype=HIT_DTYPE)
+        if hits:
+            a = np.array(hits, dtype=np.int64)
+            out["end"], out["pid"], out["k"] = a[:, 0], a[:, 1], a[:, 2]
+        return out
+
+    def pos(self):
+        return self._pos
+
+    # -- PatternMatch::reset (pattern_match.h:134) ----------------------------------------------
+    def reset(self):
+        self._check(self._L.pm_reset(self._h))
+        self._pos = 0
+
+    # -- device / host stages separately (multi-GPU path, bench) -------------------------------
+    def set_capacity(self, n):
+        self._check(self._L.pm_set_capacity(self._h, n))
+
+    def scan_candidates(self, begin, end, to_host=True):
+        n_out = C.c_size_t()
+        rc = self._L.pm_scan_candidates(self._h, begin, end, None, 0, C.byref(n_out))
+        if rc == PM_E_OVERFLOW:
+            self.set_capacity(int(n_out.value * 1.25) + 1024)
+            rc = self._L.pm_scan_candidates(self._h, begin, end, None, 0, C.byref(n_out))
+        self._check(rc)
+        if not to_host:
+            return n_out.value
+        out = np.zeros(n_out.value, dtype=HIT_DTYPE)
+        if n_out.value:
+            self._check(self._L.pm_scan_candidates(self._h, begin, end, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+        return out
+
+    def scan_async(self, begin, end):
+        self._check(self._L.pm_scan_candidates_async(self._h, begin, end))
+
+    def scan_wait(self):
+        n_out = C.c_size_t()
+        self._check(self._L.pm_scan_wait(self._h, C.byref(n_out)))
+        return n_out.value
+
+    def candidates_device(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.pm_candidates_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def finalize(self, cands, scanned_to, last=True):
+        cands = np.ascontiguousarray(cands, dtype=HIT_DTYPE)
+        out = np.zeros(max(cands.size, 1), dtype=HIT_DTYPE)
+        n_out = C.c_size_t()
+        self._check(self._L.pm_finalize(self._h, cands.ctypes.data_as(C.c_void_p), cands.size, scanned_to, int(last),
+                                        out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+    def selected(self):
+        return self._L.pm_selected_semantics(self._h), self._L.pm_selected_kernel(self._h)
+
+    def describe(self):
+        buf = C.create_string_buffer(512)
+        self._check(self._L.pm_describe(self._h, buf, 512))
+        return buf.value.decode()
+
+    def last_kernel_time(self):
+        ms, n = C.c_float(), C.c_int()
+        self._check(self._L.pm_last_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

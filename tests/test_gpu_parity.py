@@ -1,0 +1,141 @@
+"""GPU: the HIP path, called through the C ABI, against (a) the committed reference outputs in
+tests/golden and (b) the oracle on seeded random inputs.  Bit-exact (integer work)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+import sat_amd
+from oracle import pmoracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.json")) if "config1" not in p)
+SEL2SEM = {0: sat_amd.SEM_AUTO, 1: sat_amd.SEM_KEYWORD_TREE, 2: sat_amd.SEM_KEYWORD_TREE, 4: sat_amd.SEM_SHIFT_AND,
+           5: sat_amd.SEM_FILTER_BITVEC, 12: sat_amd.SEM_EXACT_HALVES, 14: sat_amd.SEM_EXACT_HALVES,
+           100: sat_amd.SEM_SHIFT_AND_INEXACT}
+KERNELS = [sat_amd.KERNEL_BITPAR]
+
+
+def gpu_hits(codes, table, patterns, sem, k, indels, kernel=sat_amd.KERNEL_BITPAR, chunk=1 << 26, esb=None, eeb=None):
+    pm = sat_amd.PatternMatch(k=k, indels=indels, semantics=sem, kernel=kernel)
+    for i, p in enumerate(patterns):
+        pm.add_pattern(p, i + 1, 0 if esb is None else esb[i], 0 if eeb is None else eeb[i])
+    pm.init(codes, table)
+    out = sat_amd.sorted_tuples(pm.find_all(chunk=chunk))
+    pm.close()
+    return out
+
+
+def load(path):
+    with open(path) as f:
+        c = json.load(f)
+    table = c["table"].encode("latin1")
+    codes = synth.normalize(synth.stream(c["entries"]), table)
+    pats = c["patterns"]
+    return c, codes, table, pats + [sat_amd.reverse_comp(p) for p in pats]
+
+
+def test_config1_known_answer():
+    with open(os.path.join(GOLD, "config1_db_test_seq.json")) as f:
+        c = json.load(f)
+    raw = np.frombuffer(c["stream_latin1"].encode("latin1"), dtype=np.uint8)
+    for sem in (sat_amd.SEM_AUTO, sat_amd.SEM_KEYWORD_TREE, sat_amd.SEM_SHIFT_AND):
+        assert gpu_hits(raw, None, c["patterns"], sem, 0, True) == [(27, 10, 0)]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_golden_engine_hits(path, kernel, monkeypatch):
+    monkeypatch.setenv("PM_BITPAR_SEGLEN", "512")      # many segments: exercises halo + ownership
+    c, codes, table, allp = load(path)
+    for name, e in c["engine"].items():
+        got = gpu_hits(codes, table, allp, SEL2SEM[e["sel"]], e["k"], e["indels"], kernel)
+        assert got == [tuple(h) for h in e["hits"]], (c["name"], name)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_vs_oracle(seed, monkeypatch):
+    monkeypatch.setenv("PM_BITPAR_SEGLEN", str([256, 768, 4096][seed % 3]))
+    rng = np.random.default_rng(77 + seed)
+    ents = synth.make_entries(rng, int(rng.integers(1, 5)), int(rng.integers(300, 3000)), n_runs=int(rng.integers(0, 4)),
+                              repeats=(seed % 2 == 0), short=(seed % 3 == 0))
+    L = int(rng.integers(12, 31))
+    pats = synth.make_patterns(rng, ents, int(rng.integers(20, 400)), length=L, planted=0.6,
+                               minlen=(L - 5 if seed % 2 else None), indel_frac=0.4)
+    table = synth.table_for(ents)
+    raw = synth.stream(ents)
+    codes = synth.normalize(raw, table)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    for norm in (True, False):
+        text = O.Text(codes, table) if norm else O.Text(np.frombuffer(raw, dtype=np.uint8))
+        data, tb = (codes, table) if norm else (np.frombuffer(raw, dtype=np.uint8), None)
+        for sem, osel, k, ind in [(sat_amd.SEM_AUTO, 0, 0, True), (sat_amd.SEM_AUTO, 0, 1, True), (sat_amd.SEM_AUTO, 0, 1, False),
+                                  (sat_amd.SEM_AUTO, 0, 2, True), (sat_amd.SEM_AUTO, 0, 2, False),
+                                  (sat_amd.SEM_SHIFT_AND_INEXACT, 100, 2, True), (sat_amd.SEM_SHIFT_AND_INEXACT, 100, 3, False),
+                                  (sat_amd.SEM_FILTER_BITVEC, 5, 1, True), (sat_amd.SEM_EXACT_HALVES, 12, 2, True)]:
+            eng = O.pick_engine(text, allp, k, ind) if osel == 0 else osel
+            want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=ind))
+            got = gpu_hits(data, tb, allp, sem, k, ind)
+            assert got == want, (seed, norm, sem, k, ind, len(want), len(got))
+
+
+def test_chunked_scan_equals_whole(monkeypatch):
+    """find_patterns is resumable: small pm_scan ranges give the same hit set,
+    including clusters and seeds that straddle range boundaries."""
+    c, codes, table, allp = load(CASES[-1])
+    for sem, k, ind in [(sat_amd.SEM_AUTO, 0, True), (sat_amd.SEM_AUTO, 1, True), (sat_amd.SEM_AUTO, 2, True), (sat_amd.SEM_AUTO, 2, False)]:
+        whole = gpu_hits(codes, table, allp, sem, k, ind)
+        for chunk in (97, 1000, 4096):
+            assert gpu_hits(codes, table, allp, sem, k, ind, chunk=chunk) == whole, (sem, k, ind, chunk)
+
+
+def test_sharded_candidates_then_finalize():
+    """The multi-GPU decomposition on one device: candidates of disjoint stream shards, merged,
+    then one pm_finalize == single scan."""
+    c, codes, table, allp = load(CASES[0])
+    n = codes.size
+    for k, ind in [(0, True), (1, True), (2, False), (2, True)]:
+        pm = sat_amd.PatternMatch(k=k, indels=ind)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        whole = sat_amd.sorted_tuples(pm.find_all())
+        pm.reset()
+        cuts = [0, n // 3 + 5, 2 * n // 3 - 7, n]
+        parts = [pm.scan_candidates(cuts[i], cuts[i + 1]) for i in range(3)]
+        merged = np.concatenate(parts[::-1])            # arrival order must not matter
+        assert sat_amd.sorted_tuples(pm.finalize(merged, n, last=True)) == whole, (k, ind)
+        pm.close()
+
+
+def test_edge_cases():
+    table = b"ACGT\n"
+    # empty stream, stream shorter than the pattern, match flush with both stream ends
+    pat = "ACGTTGCAACGTAGCT"
+    enc = lambda s: synth.normalize(s.encode(), table)
+    assert gpu_hits(np.zeros(0, dtype=np.uint8), table, [pat], sat_amd.SEM_AUTO, 0, True) == []
+    assert gpu_hits(enc("\nACGT\n"), table, [pat], sat_amd.SEM_AUTO, 2, True) == \
+        O.sorted_tuples(O.find_all(O.Text(enc("\nACGT\n"), table), [pat], engine=5, k=2, indels=True))
+    s = pat + "\n"                                   # no leading EOS: pattern starts at stream index 0
+    for k, ind, eng in [(0, True, 2), (2, False, 5), (2, True, 5), (2, True, 100), (2, False, 100)]:
+        sem = sat_amd.SEM_SHIFT_AND_INEXACT if eng == 100 else sat_amd.SEM_AUTO
+        text = O.Text(enc(s), table)
+        want = O.sorted_tuples(O.find_all(text, [pat, pat[2:] + "AC"], engine=eng, k=k, indels=ind))
+        assert gpu_hits(enc(s), table, [pat, pat[2:] + "AC"], sem, k, ind) == want, (k, ind, eng)
+
+
+def test_candidate_overflow_is_reported_and_recovered():
+    table = b"ACGT\n"
+    codes = synth.normalize(("\n" + "A" * 5000 + "\n").encode(), table)
+    pm = sat_amd.PatternMatch(k=0)
+    pm.add_pattern("AAAAAAAA", 1)
+    pm.init(codes, table)
+    pm.set_capacity(16)
+    hits = pm.find_all()
+    assert hits.size == 5000 - 8 + 1
+    pm.close()
