@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py -- primer_match scan throughput on MI355X.
+
+Metric (BASELINE.json): Gbases/s scanned, 100k x 20-mer primers (both strands, so 200k patterns),
+k <= 2 mismatches, synthetic DNA database; one "step" = one full pass of the hot path over the
+database: scan kernel(s) -> candidate records -> (N>1: RCCL gather to rank 0) -> host
+cluster/verify on rank 0 -> final hits resident on the host of rank 0.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The database is sharded by stream position across ranks: rank r holds and scans
+stream range [r*S, (r+1)*S) plus a 256-byte halo on its left; every rank holds all patterns.
+Default scaling is weak (S = --db-bases per GPU, the 3 Gbp configuration per GPU);
+--scaling strong splits a fixed --db-bases database over the ranks.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sat_amd  # noqa: E402
+
+TABLE = b"ACGT\n"           # compress_seq -n true codes: A0 C1 G2 T3 EOS4 (compress_seq.cc:704-719)
+EOS = 4
+HALO = 256
+BLOCK = 1 << 24             # generation granule: block b of the global stream is seeded with (seed, b)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 32-bit integer lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+
+def gen_stream(lo, hi, total, entries, seed, device):
+    """Codes of global stream range [lo,hi): uniform A/C/G/T with an EOS at index 0 and after each
+    of `entries` equal-length entries (layout of compress_seq's .sqn)."""
+    out = torch.empty(hi - lo, dtype=torch.uint8, device=device)
+    b0, b1 = lo // BLOCK, (hi - 1) // BLOCK
+    for b in range(b0, b1 + 1):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1000003 + b)
+        blk = torch.randint(0, 4, (BLOCK,), dtype=torch.uint8, device=device, generator=g)
+        s, e = max(lo, b * BLOCK), min(hi, (b + 1) * BLOCK)
+        out[s - lo:e - lo] = blk[s - b * BLOCK:e - b * BLOCK]
+    elen = (total - 1) // entries
+    eos_pos = torch.arange(0, entries + 1, device=device, dtype=torch.int64) * elen
+    eos_pos[-1] = total - 1
+    m = (eos_pos >= lo) & (eos_pos < hi)
+    out[(eos_pos[m] - lo)] = EOS
+    return out
+
+
+def make_primers(stream0, n_primers, L, seed):
+    """90 % i.i.d. random 20-mers, 10 % sampled from the database and given 0/1/2 substitutions
+    (SURVEY 8d).  Returns list of str."""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pri = rng.integers(0, 4, size=(n_primers, L), dtype=np.uint8)
+    n_pl = n_primers // 10
+    host = stream0.cpu().numpy()
+    placed = 0
+    while placed < n_pl:
+        a = int(rng.integers(1, host.size - L - 1))
+        w = host[a:a + L]
+        if (w > 3).any():
+            continue
+        w = w.copy()
+        for _ in range(int(rng.integers(0, 3))):
+            i = int(rng.integers(0, L))
+            w[i] = (w[i] + 1 + int(rng.integers(0, 3))) % 4
+        pri[placed] = w
+        placed += 1
+    return [lut[r].tobytes().decode() for r in pri]
+
+
+class CudaArray:
+    """Expose a raw HBM pointer to torch through __cuda_array_interface__ (for the RCCL gather)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(args, stream0, primers_fwd, log):
+    """The reference CPU path (oracle/_ref/ref_harness: pick_pattern_index's automatic engine,
+    1 thread) on a bounded sample: the same primer set against the first `sample` bases."""
+    k, indels = args.k, bool(args.indels)
+    sample = args.cpu_sample
+    if sample <= 0:
+        sample = {0: 4_000_000, 1: 2_000_000}.get(k, 48_000)
+    sample = min(sample, stream0.numel())
+    codes = stream0[:sample].cpu().numpy()
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    t0 = time.time()
+    if os.path.exists(harness):
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "db.sqn"), "wb") as f:
+                f.write(codes.tobytes())
+            with open(os.path.join(d, "db.tbl"), "wb") as f:
+                f.write(TABLE)
+            with open(os.path.join(d, "pat.txt"), "w") as f:
+                f.write("\n".join(primers_fwd) + "\n")
+            cmd = [harness, "-N", "0", "-r", "-n", "-m", "1000", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt")]
+            if k:
+                cmd += ["-k" if indels else "-K", str(k)]
+            t0 = time.time()
+            out = subprocess.run(cmd, capture_output=True, text=True)
+            dt = time.time() - t0
+            if out.returncode != 0:
+                log("cpu_baseline: ref_harness failed: " + out.stderr[-300:])
+                return None
+        kind = "reference"
+    else:
+        from oracle import pmoracle as O
+        allp = primers_fwd + [sat_amd.reverse_comp(p) for p in primers_fwd]
+        text = O.Text(codes, TABLE)
+        dt, _ = O.time_find_all(text, allp, engine=O.pick_engine(text, allp, k, indels), k=k, indels=indels)
+        kind = "port"
+    return {"value": sample / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": kind,
+            "sample": "first %d bases of the rank-0 shard, all %d primers x 2 strands, wall %.1f s incl. index build"
+                      % (sample, len(primers_fwd), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--db-bases", type=int, default=3_000_000_000, help="stream bytes per GPU (weak) or total (strong)")
+    ap.add_argument("--entries", type=int, default=24)
+    ap.add_argument("--primers", type=int, default=100_000)
+    ap.add_argument("--length", type=int, default=20)
+    ap.add_argument("--k", type=int, default=2)
+    ap.add_argument("--indels", type=int, default=0, help="0: -K (mismatches), 1: -k (edits)")
+    ap.add_argument("--kernel", choices=["auto", "bitpar", "seed"], default="auto")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="bases for the CPU baseline (0 = auto, -1 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
+
+    # ---- synthetic inputs (untimed) ----------------------------------------------------------
+    total = args.db_bases * world if args.scaling == "weak" else args.db_bases
+    shard = (total + world - 1) // world
+    lo, hi = rank * shard, min(total, (rank + 1) * shard)
+    glo = max(0, lo - HALO)
+    stream = gen_stream(glo, hi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev)
+    n_bases_total = total - (args.entries * (world if args.scaling == "weak" else 1) + 1)
+    if rank == 0:
+        primers = make_primers(stream[:min(stream.numel(), 1 << 26)], args.primers, args.length, 7)
+    else:
+        primers = None
+    if world > 1:
+        box = [primers]
+        dist.broadcast_object_list(box, src=0)
+        primers = box[0]
+    allp = primers + [sat_amd.reverse_comp(p) for p in primers]
+    kern = {"auto": sat_amd.KERNEL_AUTO, "bitpar": sat_amd.KERNEL_BITPAR, "seed": sat_amd.KERNEL_SEED}[args.kernel]
+    pm = sat_amd.PatternMatch(k=args.k, indels=bool(args.indels), kernel=kern, device=local)
+    for i, p in enumerate(allp):
+        pm.add_pattern(p, i + 1)
+    t0 = time.time()
+    pm.init_device(stream.data_ptr(), stream.numel(), TABLE, stream=torch.cuda.current_stream().cuda_stream, keepalive=stream)
+    pm.set_capacity(1 << 24)
+    log("index build %.2f s; semantics=%s kernel=%s" % (time.time() - t0, *pm.selected()))
+    begin, end = lo - glo, hi - glo
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms = []
+    final_hits = [0]
+    cand_count = [0]
+
+    def step():
+        pm.scan_async(begin, end)
+        ncand = pm.scan_wait()
+        ms, _ = pm.last_kernel_time()
+        kernel_ms.append(ms)
+        ptr, cnt = pm.candidates_device()
+        if world == 1:
+            cands = np.zeros(cnt, dtype=sat_amd.HIT_DTYPE)
+            if cnt:
+                t = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev)
+                cands = t.cpu().numpy().view(sat_amd.HIT_DTYPE)
+        else:
+            # the path's one real exchange: variable-length hit records to rank 0 over xGMI
+            counts = torch.zeros(world, dtype=torch.int64, device=dev)
+            mine = torch.tensor([cnt], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(counts, mine)
+            mx = int(counts.max().item())
+            pad = torch.zeros(max(mx, 1) * 16, dtype=torch.uint8, device=dev)
+            if cnt:
+                pad[:cnt * 16] = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev)
+            gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, gathered, dst=0)
+            cands = None
+            if rank == 0:
+                parts = []
+                cl = counts.cpu().tolist()
+                for r in range(world):
+                    a = gathered[r][:cl[r] * 16].cpu().numpy().view(sat_amd.HIT_DTYPE).copy()
+                    a["end"] += max(0, r * shard - HALO)                    # local -> global stream index
+                    parts.append(a)
+                cands = np.concatenate(parts) if parts else np.zeros(0, dtype=sat_amd.HIT_DTYPE)
+        if rank == 0:
+            cand_count[0] = cands.size
+            if world == 1:
+                hits = pm.finalize(cands, end, last=True)
+            else:
+                hits = finalize_global(cands)
+            final_hits[0] = hits.size
+        return ncand
+
+    def finalize_global(cands):
+        # rank 0 only sees its own shard's text; the default -K search needs no text to cluster
+        # (levels decide), see DESIGN.md "multi-GPU finalize"
+        if pm.selected()[0] not in (sat_amd.SEM_KEYWORD_TREE, sat_amd.SEM_SHIFT_AND, sat_amd.SEM_SHIFT_AND_INEXACT) and \
+                not (pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC and not args.indels):
+            raise SystemExit("bench.py --gpus>1: this option set needs stream text in the verify stage; "
+                             "supported multi-GPU runs are k=0 and -K k (see DESIGN.md)")
+        pm.reset()
+        return pm.finalize(cands, int(cands["end"].max()) + 1 if cands.size else 0, last=True)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n_bases_total / (dt / args.steps) / 1e9
+        kms = float(np.mean(kernel_ms[args.warmup:])) if len(kernel_ms) > args.warmup else float("nan")
+        shard_bytes = end - begin
+        alg_bytes = shard_bytes + 16 * cand_count[0] / max(world, 1)
+        achieved = alg_bytes / (kms * 1e-3) / 1e9
+        desc = pm.describe()
+        res = {
+            "metric": "Gbases/s scanned, 100k x 20-mer primers k<=2, 3 Gbp DB",
+            "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%d x %d-mer primers, both strands (%d patterns), %s %d, %s Gbp stream per GPU x %d GPU(s), %d entries"
+                                   % (args.primers, args.length, len(allp), "-k" if args.indels else "-K", args.k,
+                                      ("%.3g" % (shard / 1e9)), world, args.entries),
+                       "semantics": pm.selected()[0], "kernel_family": pm.selected()[1], "kernel": desc,
+                       "final_hits": final_hits[0], "candidates": cand_count[0]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kms, "algorithmic_bytes": alg_bytes},
+        }
+        if not args.no_cpu and args.cpu_sample >= 0 and world == 1:
+            cb = cpu_baseline(args, stream, primers, log)
+            if cb:
+                res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    pm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 #include <new>
 
 #include "pm_internal.h"
+#include "pm_seed.h"
 
 using namespace pm;
 
@@ -49,13 +50,16 @@ struct pm_handle {
   std::vector<Pattern> inner;
   std::vector<uint32_t> inner_ids;
   BitparDevice bp;
-  int scan_k = 0;
+  SeedDevice sd;
+  bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
+  int scan_k = 0, seed_k = 0;
   bool scan_indels = false;
   pm_hit *d_cands = nullptr;
   unsigned long long *d_counter = nullptr;
   unsigned long long *h_counter = nullptr;     // pinned
   size_t cap = 0;
   size_t last_count = 0;
+  int64_t scan_begin = 0;
   bool scan_pending = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
@@ -138,6 +142,7 @@ extern "C" int pm_add_pattern(pm_handle *h, const char *pat, size_t len, uint64_
 
 static void free_device(pm_handle *h) {
   bitpar_free(&h->bp);
+  seed_free(&h->sd);
   if (h->d_cands) (void)hipFree(h->d_cands);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -220,11 +225,19 @@ static int resolve(pm_handle *h) {
       }
       break;
   }
-  int kern = h->cfg.kernel;
-  if (kern == PM_KERNEL_AUTO) kern = PM_KERNEL_BITPAR;
-  if (kern != PM_KERNEL_BITPAR) return fail(h, PM_E_UNSUPPORTED, "seed kernel family is not available in this build");
-  h->kern = kern;
+  h->kern = h->cfg.kernel;
   return PM_OK;
+}
+
+// Inner pattern set of the seed family: Hamming candidates of the WHOLE patterns; the wrappers'
+// rules are then applied to (end, pattern, distance, clean-half flags) records on the host.
+static bool seed_eligible(pm_handle *h, std::string *why) {
+  const int sem = h->sem;
+  if (h->cfg.k > 0 && h->cfg.indels && sem != PM_SEM_KEYWORD_TREE && sem != PM_SEM_SHIFT_AND) { *why = "edit-distance search (-k) runs on the bit-parallel family"; return false; }
+  if (sem == PM_SEM_EXACT_BASES) { *why = "exact_bases runs on the bit-parallel family"; return false; }
+  if (sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_EXACT_HALVES)
+    for (const Pattern &p : h->pats) if (p.esb || p.eeb) { *why = "exact-base constraints need the text-based verify of the bit-parallel family"; return false; }
+  return true;
 }
 
 static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
@@ -235,10 +248,41 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->eos_code = h->alpha.nch[(uint8_t)h->cfg.eos];                  // shift_and_inexact.cc:131
   int rc = resolve(h);
   if (rc) return rc;
-  BitparTables tabs;
-  std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs);
-  if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine: " + msg);
-  HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
+  bitpar_free(&h->bp); seed_free(&h->sd);
+  h->seed_flags = false;
+  std::string why;
+  bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
+  if (want_seed && !seed_eligible(h, &why)) {
+    if (h->kern == PM_KERNEL_SEED) return fail(h, PM_E_UNSUPPORTED, "seed engine: " + why);
+    want_seed = false;
+  }
+  if (want_seed) {
+    std::vector<Pattern> sp; std::vector<uint32_t> sid;
+    int sk = h->scan_k;
+    if (h->sem == PM_SEM_EXACT_HALVES) {          // whole patterns, distance <= k, halves decided by flags
+      for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back((uint32_t)(i + 1)); }
+      sk = h->cfg.k;
+    } else { sp = h->inner; sid = h->inner_ids; }
+    SeedTables st;
+    why = seed_build(sp, sid, h->alpha, sk, h->eos_code, &st);
+    if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < 10) why = "patterns shorter than 10";
+    if (!why.empty()) {
+      if (h->kern == PM_KERNEL_SEED) return fail(h, PM_E_UNSUPPORTED, "seed engine: " + why);
+      want_seed = false;
+    } else {
+      HIP_TRY(h, seed_upload(st, &h->sd, h->stream));
+      h->kern = PM_KERNEL_SEED;
+      h->seed_flags = h->sem == PM_SEM_EXACT_HALVES;
+      h->seed_k = sk;
+    }
+  }
+  if (!want_seed) {
+    h->kern = PM_KERNEL_BITPAR;
+    BitparTables tabs;
+    std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs);
+    if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine: " + msg);
+    HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
+  }
   if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, sizeof(unsigned long long)));
   if (!h->h_counter) HIP_TRY(h, hipHostMalloc((void **)&h->h_counter, sizeof(unsigned long long), hipHostMallocDefault));
   if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
@@ -297,9 +341,14 @@ extern "C" int pm_selected_kernel(const pm_handle *h) { return h && h->inited ? 
 
 extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   if (!h || !buf || !h->inited) return PM_E_INVALID;
-  snprintf(buf, buflen, "kernel=%s tiles=%d lanes_per_tile=64 words_per_lane=%d seg_len=%lld nseg=%d grid=%d block=%d",
-           bitpar_kernel_name(h->scan_k, h->scan_indels), h->bp.ntiles, BP_WPL, (long long)h->geo.seg_len, h->geo.nseg,
-           h->geo.blocks, h->geo.threads);
+  if (h->kern == PM_KERNEL_SEED)
+    snprintf(buf, buflen, "kernel=pm_seed_scan combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
+             h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
+             h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
+  else
+    snprintf(buf, buflen, "kernel=%s tiles=%d lanes_per_tile=64 words_per_lane=%d seg_len=%lld nseg=%d grid=%d block=%d",
+             bitpar_kernel_name(h->scan_k, h->scan_indels), h->bp.ntiles, BP_WPL, (long long)h->geo.seg_len, h->geo.nseg,
+             h->geo.blocks, h->geo.threads);
   return PM_OK;
 }
 
@@ -311,11 +360,53 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-  HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
+  if (h->kern == PM_KERNEL_SEED)
+    HIP_TRY(h, seed_launch(h->sd, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
+  else
+    HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
+  h->scan_begin = begin;
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   h->last_launches = 1;
   h->scan_pending = true;
+  return PM_OK;
+}
+
+// The k-error automaton starts with the first l bits of every pattern set in row l
+// (shift_and_inexact.cc:162-164), so at the very start of the stream a pattern whose first
+// d <= k characters are "missing" is reported at end = L-d with level d + mismatches.  The seed
+// kernel only sees whole windows; these few records are produced here and appended in HBM.
+static int stream_start_candidates(pm_handle *h) {
+  const int k = h->seed_k;
+  const int64_t need = std::min<int64_t>(h->n, 32);
+  uint8_t head[32] = {0};
+  if (need > 0) {
+    if (h->h_text) memcpy(head, h->h_text, (size_t)need);
+    else HIP_TRY(h, hipMemcpy(head, h->d_text, (size_t)need, hipMemcpyDeviceToHost));
+  }
+  std::vector<pm_hit> extra;
+  for (size_t j = 0; j < h->inner.size(); ++j) {
+    const std::string &s = h->inner[j].s;
+    const int L = (int)s.size();
+    for (int d = 1; d <= k && d < L; ++d) {
+      const int e = L - d;
+      if (e > h->n) continue;
+      int lvl = d;
+      bool dead = false;
+      for (int i = 0; i < e && !dead; ++i) {
+        if ((int)head[i] == h->eos_code) dead = true;                // EOS clears every row
+        else if ((int)head[i] != h->alpha.nch[(unsigned char)s[d + i]]) ++lvl;
+      }
+      if (!dead && lvl <= k) {
+        pm_hit x; x.end = e; x.pid = h->inner_ids[j]; x.k = (uint8_t)lvl; x.aux[0] = x.aux[1] = x.aux[2] = 0;
+        extra.push_back(x);
+      }
+    }
+  }
+  if (extra.empty()) return PM_OK;
+  if (h->last_count + extra.size() > h->cap) return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)");
+  HIP_TRY(h, hipMemcpy(h->d_cands + h->last_count, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
+  h->last_count += extra.size();
   return PM_OK;
 }
 
@@ -328,6 +419,12 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   if (n_out) *n_out = cnt;
   if (cnt > h->cap) { h->last_count = 0; return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
   h->last_count = cnt;
+  if (h->kern == PM_KERNEL_SEED && h->scan_begin == 0 && h->seed_k > 0 &&
+      (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT)) {
+    int rc = stream_start_candidates(h);
+    if (rc) return rc;
+    if (n_out) *n_out = h->last_count;
+  }
   return PM_OK;
 }
 
@@ -540,6 +637,40 @@ int finalize_seeds(pm_handle *h, const pm_hit *cands, size_t n, bool halves, std
   return PM_OK;
 }
 
+// exact_halves on whole-pattern Hamming candidates (seed family, -K only): a candidate whose left
+// half is clean was found by the reference through the left seed at end-len2 (inner id 2j-1), one
+// whose right half is clean through the right seed at end (inner id 2j); both report
+// (end, distance) (primer_alignment.cc:568-617, 651-704 with indels off).  Seeds are then
+// replayed in the reference's order (position asc, inner id desc) through the per-pattern
+// "end > last kept end" rule (exact_halves.cc:114-118,163,178).
+int finalize_halves_flags(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
+                          std::vector<pm_hit> &outv) {
+  // a seed is kept in h->carry as {end = seed position, pid = inner id, k = value, aux[0] = end - position}
+  std::vector<pm_hit> &seeds = h->carry;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t j = cands[i].pid;                                // 1-based pattern index
+    const int L = (int)h->pats[j - 1].s.size();
+    const int len2 = L - L / 2;
+    if (cands[i].aux[0] & 1) { pm_hit x = make_hit(cands[i].end - len2, 2 * j - 1, cands[i].k); x.aux[0] = (uint8_t)len2; seeds.push_back(x); }
+    if (cands[i].aux[0] & 2) seeds.push_back(make_hit(cands[i].end, 2 * j, cands[i].k));
+  }
+  std::sort(seeds.begin(), seeds.end(), seed_order);
+  // candidates still to come end beyond scanned_to, so their seeds lie beyond scanned_to - maxlen:
+  // everything at or before that is in its final order
+  const int64_t safe = last ? INT64_MAX : scanned_to - h->sd.maxlen;
+  size_t i = 0;
+  for (; i < seeds.size() && seeds[i].end <= safe; ++i) {
+    const uint32_t j = (seeds[i].pid + 1) / 2;
+    const int64_t end = seeds[i].end + seeds[i].aux[0];
+    if (end > h->lasthit[j]) {
+      outv.push_back(make_hit(end, h->pats[j - 1].id, seeds[i].k));
+      h->lasthit[j] = end;
+    }
+  }
+  seeds.erase(seeds.begin(), seeds.begin() + i);
+  return PM_OK;
+}
+
 }  // namespace
 
 static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
@@ -550,7 +681,7 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
       outv.insert(outv.end(), cands, cands + n);
       break;
     case PM_SEM_FILTER_BITVEC: rc = finalize_filter_bitvec(h, cands, n, scanned_to, last, outv); break;
-    case PM_SEM_EXACT_HALVES: rc = finalize_seeds(h, cands, n, true, outv); break;
+    case PM_SEM_EXACT_HALVES: rc = h->seed_flags ? finalize_halves_flags(h, cands, n, scanned_to, last, outv) : finalize_seeds(h, cands, n, true, outv); break;
     case PM_SEM_EXACT_BASES: rc = finalize_seeds(h, cands, n, false, outv); break;
     default: return fail(h, PM_E_INVALID, "finalize: bad semantics");
   }

@@ -1,0 +1,52 @@
+// pm_seed.h -- seed-filter kernel family (pm_seed.hip): host tables and launch interface.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pm_internal.h"
+
+namespace pm {
+
+constexpr int SEED_THREADS = 1024;                // 16 waves per workgroup, one workgroup per CU (LDS bound)
+constexpr int SEED_QCAP = 192;                    // survivor queue entries per wave
+constexpr int SEED_BLOOM_WORDS = 32768;           // 128 KiB blocked Bloom filter per combo
+constexpr int SEED_MAX_COMBOS = 16;
+constexpr int SEED_LDS_BYTES = SEED_BLOOM_WORDS * 4 + (SEED_THREADS / 64) * SEED_QCAP * 8;   // filter + wave queues
+
+struct SeedTables {
+  int k = 0, Lw = 0, pb = 0, r = 0, maxlen = 0;
+  bool ascii = false;
+  std::vector<std::array<int, 4>> combos;         // piece indices of every combo
+  size_t nslots = 0;
+  std::vector<uint32_t> bloom;                    // [combo][SEED_BLOOM_WORDS]
+  std::vector<uint32_t> slots;                    // [combo][nslots][2]
+  struct P40 { uint32_t lo, hi; };
+  std::vector<P40> pat40;
+  std::vector<uint8_t> pat_len;
+  std::vector<uint32_t> pat_id;
+  std::vector<uint8_t> pat_codes;                 // 32 bytes per pattern
+  uint8_t cmap[256];
+};
+
+struct SeedDevice {
+  uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr;
+  void *pat40 = nullptr;
+  uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr;
+  uint32_t piece_shift[SEED_MAX_COMBOS][4] = {};
+  int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;
+  bool ascii = false;
+  size_t nslots = 0;
+};
+
+std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
+                       const Alphabet &alpha, int k, int eos_code, SeedTables *out);
+hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
+void seed_free(SeedDevice *d);
+ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);
+hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
+                       pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
+                       ScanGeometry *geo_out);
+
+}  // namespace pm

@@ -1,0 +1,422 @@
+// pm_seed.hip -- seed-filter scan kernel for gfx950: 2-bit packed windows, per-combo Bloom filter
+// in LDS, ballot/popcount compaction of survivors, hash-table verify.
+//
+// What it computes: every (end, pattern, d) with d = Hamming(stream window, pattern) <= k and no
+// EOS inside the window -- the hit set of the reference's exact engines for k = 0
+// (keyword_tree.t:427-486, shift_and.cc:208-255) and the candidate set of its substitution-only
+// k-error automaton (shift_and_inexact.cc:249-352 with indels=false), on which filter_bitvec and
+// exact_halves build.  Patterns are A/C/G/T strings of <= 32 characters.
+//
+// How (pigeonhole, DESIGN.md "seed family"): the last Lw characters of every pattern are cut into
+// m = k + r pieces of pb characters; <= k substitutions leave >= r pieces untouched, so a true
+// candidate agrees with the pattern on at least one of the C(m,r) piece combinations ("combos").
+//   * a WORKGROUP owns one (combo, stream chunk): it stages that combo's 128 KiB blocked Bloom
+//     filter (3 bits per key inside one dword) in LDS, then streams its chunk;
+//   * a LANE loads 16 stream bytes with one 16-byte load (a wave reads 1 KiB contiguous), packs
+//     them to 2 bits per base, borrows the previous 32 bases from its neighbours with two wave
+//     shuffles, and tests its 16 windows: funnel shift -> combo key -> one ds_read_b32;
+//   * survivors (~9 % per test) are compacted wave-wide with ballot + mbcnt into a per-wave LDS
+//     queue, so the second stage runs on full waves: probe the combo's open-addressing table
+//     (8-byte slots, L2 resident: consecutive workgroups work on the same combo), XOR + popcount
+//     the packed window against the pattern, and only then re-read the raw stream bytes for the
+//     exact distance (N = mismatch, EOS = reject);
+//   * a (window, pattern) pair reachable through several combos is reported by exactly one: the
+//     combo made of its first r clean pieces.
+//
+// Cost model: ~25 VALU + 1 LDS read per (position, combo), ~0.9*C/10 L2 probes per position.
+// Bound: LDS/VALU issue, then L2 request rate; HBM traffic is 1 byte per base per MALL pass.
+#include "pm_internal.h"
+#include "pm_seed.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace pm {
+
+namespace {
+
+constexpr int QCAP = SEED_QCAP;                // queue entries per wave (8 B each)
+constexpr int WAVES = SEED_THREADS / 64;  // 8
+constexpr uint32_t EMPTY = 0xffffffffu;
+
+struct SeedArgs {
+  const uint8_t *text;
+  int64_t n, begin, end;                // owned hit ends: begin < end_pos <= end
+  int64_t chunk0;                       // first chunk index (absolute, chunk_len aligned)
+  int64_t chunk_len;                    // bytes per workgroup, multiple of 1024*WAVES
+  int nchunks, ncombos, group;          // group = chunks per (superchunk, combo) run
+  int k, Lw, pb, r, ascii;
+  uint32_t piece_shift[SEED_MAX_COMBOS][4];   // bit offset of each piece of a combo inside the window
+  uint32_t pmask;                       // (1 << 2*pb) - 1
+  const uint32_t *bloom;                // [combo][SEED_BLOOM_WORDS]
+  const uint2 *slots;                   // [combo][nslots]  {key, pattern index}
+  uint32_t slot_mask;
+  const uint2 *pat40;                   // packed last Lw bases of every pattern
+  const uint8_t *pat_len;
+  const uint32_t *pat_id;
+  const uint8_t *pat_codes;             // stream codes of every pattern char, 32 bytes per pattern
+  const uint8_t *cmap;                  // stream code -> 0 ok, 1 EOS (anything else is just a code)
+  pm_hit *out;
+  unsigned long long *counter;
+  unsigned long long cap;
+};
+
+__device__ __forceinline__ uint32_t pack4(uint32_t x, int sh) {
+  // 4 stream bytes -> 8 bits, 2 bits per base (byte 0 in bits 0-1)
+  uint32_t y = (x >> sh) & 0x03030303u;
+  y |= y >> 6;
+  return (y | (y >> 12)) & 0xffu;
+}
+
+__device__ __forceinline__ uint32_t pack16(const uint4 &v, int sh) {
+  return pack4(v.x, sh) | (pack4(v.y, sh) << 8) | (pack4(v.z, sh) << 16) | (pack4(v.w, sh) << 24);
+}
+
+__device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_t n) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (off >= 0 && off + 16 <= n) v = *reinterpret_cast<const uint4 *>(text + off);
+  else {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 16; ++b) {
+      const int64_t p = off + b;
+      if (p >= 0 && p < n) w[b >> 2] |= (uint32_t)text[p] << (8 * (b & 3));
+    }
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t combo_key(uint32_t wlo, uint32_t whi, const SeedArgs &a, int combo) {
+  const uint64_t W = ((uint64_t)whi << 32) | wlo;
+  uint32_t key = 0;
+  for (int t = 0; t < a.r; ++t)
+    key |= ((uint32_t)(W >> a.piece_shift[combo][t]) & a.pmask) << (2 * a.pb * t);
+  return key;
+}
+
+__device__ __forceinline__ uint32_t bloom_mask(uint32_t h) {
+  return (1u << ((h >> 12) & 31)) | (1u << ((h >> 7) & 31)) | (1u << ((h >> 2) & 31));
+}
+
+// Second and third stage for one queued window.
+__device__ __forceinline__ void verify_entry(const SeedArgs &a, int combo, uint32_t wlo, uint32_t whi, int64_t p) {
+  const uint32_t key = combo_key(wlo, whi, a, combo);
+  const uint2 *slots = a.slots + (size_t)combo * (a.slot_mask + 1);
+  uint32_t idx = (key * 0x85EBCA6Bu) >> 7 & a.slot_mask;
+  const uint64_t W = ((uint64_t)whi << 32) | wlo;
+  for (;;) {
+    const uint2 s = slots[idx];
+    if (s.y == EMPTY) break;
+    idx = (idx + 1) & a.slot_mask;
+    if (s.x != key) continue;
+    const uint32_t pi = s.y;
+    const uint2 pp = a.pat40[pi];
+    const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
+    const uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ull;
+    if (__popcll(mm) > a.k) continue;                 // packed distance never exceeds the true one
+    // exact distance on the raw stream codes
+    const int L = a.pat_len[pi];
+    const int64_t start = p + 1 - L;
+    if (start < 0) continue;
+    const uint8_t *pc = a.pat_codes + (size_t)pi * 32;
+    int ham = 0;
+    uint32_t dirty = 0;                               // pieces (of the last Lw bases) with a mismatch
+    bool left_clean = true, right_clean = true, dead = false;
+    for (int i = 0; i < L; ++i) {
+      const uint8_t tc = a.text[start + i];
+      if (a.cmap[tc] == 1) { dead = true; break; }    // EOS inside the window: never a candidate
+      if (tc != pc[i]) {
+        if (++ham > a.k) { dead = true; break; }
+        if (i < L / 2) left_clean = false; else right_clean = false;
+        const int j = i - (L - a.Lw);                 // position inside the seeded suffix
+        if (j >= 0 && j / a.pb < a.k + a.r) dirty |= 1u << (j / a.pb);
+      }
+    }
+    if (dead) continue;
+    // report once: only through the combo made of the first r clean pieces
+    bool mine = true;
+    {
+      int t = 0;
+      const int m = a.k + a.r;
+      for (int j = 0; j < m && t < a.r; ++j) {
+        if (dirty >> j & 1) continue;
+        if (a.piece_shift[combo][t] != (uint32_t)(2 * a.pb * j)) { mine = false; break; }
+        ++t;
+      }
+    }
+    if (!mine) continue;
+    const unsigned long long o = atomicAdd(a.counter, 1ull);
+    if (o < a.cap) {
+      pm_hit h;
+      h.end = p + 1; h.pid = a.pat_id[pi]; h.k = (uint8_t)ham;
+      h.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); h.aux[1] = h.aux[2] = 0;
+      a.out[o] = h;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
+  extern __shared__ uint32_t lds[];
+  uint32_t *bloom = lds;                                          // SEED_BLOOM_WORDS dwords
+  uint2 *queue_all = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_WORDS);
+
+  // blockIdx -> (combo, chunk): runs of `group` chunks share a combo, all combos of a superchunk
+  // follow each other, so the stream bytes of a superchunk are re-read from MALL and the combo's
+  // slot table stays in every XCD's L2 while a run is in flight.
+  const int per_super = a.group * a.ncombos;
+  const int sc = blockIdx.x / per_super;
+  const int rem = blockIdx.x - sc * per_super;
+  int combo = rem / a.group;
+  int cj = sc * a.group + (rem - combo * a.group);
+  const int full = (a.nchunks / a.group) * a.group;               // last, shorter superchunk
+  if (sc * a.group >= full) {
+    const int tail = a.nchunks - full;
+    const int r2 = blockIdx.x - (full / a.group) * per_super;
+    combo = r2 / tail;
+    cj = full + (r2 - combo * tail);
+  }
+  if (cj >= a.nchunks || combo >= a.ncombos) return;
+
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.bloom + (size_t)combo * SEED_BLOOM_WORDS);
+    uint4 *dst = reinterpret_cast<uint4 *>(bloom);
+    for (int i = threadIdx.x; i < SEED_BLOOM_WORDS / 4; i += SEED_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint2 *queue = queue_all + wave * QCAP;
+  const int64_t sub = a.chunk_len / WAVES;
+  const int64_t ws = (a.chunk0 + cj) * a.chunk_len + (int64_t)wave * sub;   // first base of this wave
+  int64_t own_lo = ws > a.begin ? ws : a.begin;                   // p = index of the window's last base
+  int64_t own_hi = ws + sub;
+  if (own_hi > a.end) own_hi = a.end;
+  if (own_hi > a.n) own_hi = a.n;
+  if (own_lo < a.Lw - 1) own_lo = a.Lw - 1;                       // the window must fit in the stream
+  if (own_lo >= own_hi) return;
+
+  const int sh = a.ascii ? 1 : 0;
+  // the 32 bases in front of the wave's range
+  uint32_t carry1, carry2;
+  {
+    const uint4 v = load16(a.text, ws - 32 + 16 * (lane & 1), a.n);
+    const uint32_t pk = pack16(v, sh);
+    carry2 = __builtin_amdgcn_readlane(pk, 0);
+    carry1 = __builtin_amdgcn_readlane(pk, 1);
+  }
+  const int wbits = 2 * a.Lw;
+  const uint32_t lo_mask = wbits >= 32 ? 0xffffffffu : ((1u << wbits) - 1u);
+  const uint32_t hi_mask = wbits > 32 ? ((1u << (wbits - 32)) - 1u) : 0u;
+  int qn = 0;                                                     // wave-uniform queue fill
+
+  for (int64_t bb = ws; bb < own_hi; bb += 1024) {
+    const uint4 v = load16(a.text, bb + 16 * lane, a.n);
+    const uint32_t cur = pack16(v, sh);
+    uint32_t prev1 = __shfl_up(cur, 1), prev2 = __shfl_up(cur, 2);
+    if (lane == 0) { prev1 = carry1; prev2 = carry2; }
+    if (lane == 1) prev2 = carry1;
+    carry2 = __builtin_amdgcn_readlane(cur, 62);
+    carry1 = __builtin_amdgcn_readlane(cur, 63);
+    const uint64_t A = ((uint64_t)prev1 << 32) | prev2, B = ((uint64_t)cur << 32) | prev1;
+    const int64_t pbase = bb + 16 * lane;
+    const bool last_block = bb + 1024 >= own_hi;
+    int i = 0;
+    for (;;) {
+      // first stage: 64 windows per step, until the queue could overflow
+      for (; i < 16 && qn + 64 <= QCAP; ++i) {
+        const int s = 2 * (i - a.Lw + 33);                         // bit offset of the window in prev2:prev1:cur
+        uint32_t wlo, whi;
+        if (s < 32) { wlo = (uint32_t)(A >> s); whi = (uint32_t)(B >> s); }
+        else { wlo = (uint32_t)(B >> (s - 32)); whi = cur >> (s - 32); }
+        wlo &= lo_mask; whi &= hi_mask;
+        const uint32_t key = combo_key(wlo, whi, a, combo);
+        const uint32_t h = key * 0x9E3779B1u;
+        const uint32_t word = bloom[h >> 17];
+        const uint32_t bm = bloom_mask(h);
+        const int64_t p = pbase + i;
+        const bool pass = ((word & bm) == bm) && p >= own_lo && p < own_hi;
+        const unsigned long long bal = __ballot(pass);
+        if (pass) {
+          const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+          queue[slot] = make_uint2(wlo, whi | ((uint32_t)(p - ws) << 8));
+        }
+        qn += __popcll(bal);
+      }
+      // second stage on full waves of survivors (single call site: the body is large)
+      if (qn + 64 > QCAP || (i == 16 && last_block)) {
+        for (int q = lane; q < qn; q += 64) {
+          const uint2 e = queue[q];
+          verify_entry(a, combo, e.x, e.y & 0xffu, ws + (e.y >> 8));
+        }
+        qn = 0;
+      }
+      if (i == 16) break;
+    }
+  }
+}
+
+}  // namespace
+
+// ---- host side: plan, tables, launch ------------------------------------------------------------
+
+static uint64_t binom(int n, int r) {
+  uint64_t v = 1;
+  for (int i = 1; i <= r; ++i) v = v * (n - r + i) / i;
+  return v;
+}
+
+std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
+                       const Alphabet &alpha, int k, int eos_code, SeedTables *out) {
+  SeedTables &t = *out;
+  t = SeedTables();
+  t.k = k;
+  if (k < 0 || k > 3) return "seed kernels are built for k <= 3";
+  // stream packing: codes 0..3 = A,C,G,T (compress_seq -n true) or raw ASCII ((c >> 1) & 3)
+  const bool norm = alpha.nch['A'] == 0 && alpha.nch['C'] == 1 && alpha.nch['G'] == 2 && alpha.nch['T'] == 3;
+  const bool ascii = alpha.size == 256 && alpha.nch['A'] == 'A' && alpha.nch['C'] == 'C' && alpha.nch['G'] == 'G' && alpha.nch['T'] == 'T';
+  if (!norm && !ascii) return "stream alphabet is neither A,C,G,T-normalized nor raw ASCII";
+  t.ascii = ascii && !norm;
+  auto base2 = [&](unsigned char ch) -> int {
+    switch (ch) { case 'A': return t.ascii ? 0 : 0; case 'C': return 1; case 'G': return t.ascii ? 3 : 2; case 'T': return t.ascii ? 2 : 3; }
+    return -1;
+  };
+  int lmin = 1 << 30, lmax = 0;
+  for (const Pattern &p : pats) {
+    if (p.s.empty()) return "empty pattern";
+    if (p.s.size() > 32) return "pattern longer than 32 characters";
+    for (unsigned char ch : p.s) if (base2(ch) < 0) return "pattern with characters other than A,C,G,T";
+    lmin = std::min(lmin, (int)p.s.size()); lmax = std::max(lmax, (int)p.s.size());
+  }
+  if (pats.empty()) { lmin = lmax = 1; }
+  t.maxlen = lmax;
+  t.Lw = std::min(lmin, 20);
+  // choose m = k + r pieces of pb bases: fewest filter lookups + verifies
+  double best = 1e300;
+  const double P = std::max<size_t>(pats.size(), 1);
+  for (int r = 1; r <= 4; ++r) {
+    const int m = k + r, pb = t.Lw / m;
+    if (pb < 1 || r * pb > 16 || m > 8) continue;
+    const double C = (double)binom(m, r);
+    if (C > SEED_MAX_COMBOS) continue;
+    double keys = 1; for (int i = 0; i < r * pb; ++i) keys *= 4;
+    const double cost = C * 1.1 + 20.0 * C * P / keys;
+    if (cost < best) { best = cost; t.r = r; t.pb = pb; }
+  }
+  if (best > 1e299) return "patterns too short for a k-mismatch seed plan";
+  const int m = k + t.r;
+  // enumerate combos (r-subsets of m pieces) in lexicographic order
+  std::vector<int> c(t.r);
+  for (int i = 0; i < t.r; ++i) c[i] = i;
+  for (;;) {
+    std::array<int, 4> cc = {0, 0, 0, 0};
+    for (int i = 0; i < t.r; ++i) cc[i] = c[i];
+    t.combos.push_back(cc);
+    int i = t.r - 1;
+    while (i >= 0 && c[i] == m - t.r + i) --i;
+    if (i < 0) break;
+    ++c[i];
+    for (int j = i + 1; j < t.r; ++j) c[j] = c[j - 1] + 1;
+  }
+  const int C = (int)t.combos.size();
+  const size_t np = pats.size();
+  t.pat40.resize(np); t.pat_len.resize(np); t.pat_id.resize(np); t.pat_codes.assign(np * 32, 0);
+  size_t nslots = 1024;
+  while (nslots < 2 * np) nslots <<= 1;
+  t.nslots = nslots;
+  t.bloom.assign((size_t)C * SEED_BLOOM_WORDS, 0);
+  t.slots.assign((size_t)C * nslots * 2, EMPTY);
+  for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
+  if (eos_code >= 0 && eos_code < 256) t.cmap[eos_code] = 1;
+  const uint32_t pmask = (1u << (2 * t.pb)) - 1u;
+  for (size_t j = 0; j < np; ++j) {
+    const std::string &s = pats[j].s;
+    const int L = (int)s.size();
+    uint64_t w = 0;
+    for (int i = 0; i < t.Lw; ++i) w |= (uint64_t)base2((unsigned char)s[L - t.Lw + i]) << (2 * i);
+    t.pat40[j] = {(uint32_t)w, (uint32_t)(w >> 32)};
+    t.pat_len[j] = (uint8_t)L;
+    t.pat_id[j] = ids[j];
+    for (int i = 0; i < L; ++i) t.pat_codes[j * 32 + i] = (uint8_t)alpha.nch[(unsigned char)s[i]];
+    for (int ci = 0; ci < C; ++ci) {
+      uint32_t key = 0;
+      for (int q = 0; q < t.r; ++q) key |= ((uint32_t)(w >> (2 * t.pb * t.combos[ci][q])) & pmask) << (2 * t.pb * q);
+      const uint32_t h = key * 0x9E3779B1u;
+      t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h >> 17)] |= (1u << ((h >> 12) & 31)) | (1u << ((h >> 7) & 31)) | (1u << ((h >> 2) & 31));
+      uint32_t idx = ((key * 0x85EBCA6Bu) >> 7) & (uint32_t)(nslots - 1);
+      uint32_t *sl = &t.slots[(size_t)ci * nslots * 2];
+      while (sl[2 * idx + 1] != EMPTY) idx = (idx + 1) & (uint32_t)(nslots - 1);
+      sl[2 * idx] = key; sl[2 * idx + 1] = (uint32_t)j;
+    }
+  }
+  return "";
+}
+
+hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
+  seed_free(d);
+  d->k = t.k; d->Lw = t.Lw; d->pb = t.pb; d->r = t.r; d->ascii = t.ascii; d->maxlen = t.maxlen;
+  d->ncombos = (int)t.combos.size(); d->nslots = t.nslots;
+  for (int c = 0; c < d->ncombos; ++c)
+    for (int q = 0; q < 4; ++q) d->piece_shift[c][q] = (uint32_t)(2 * t.pb * t.combos[c][q]);
+  auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+  };
+  hipError_t e;
+  if ((e = up(t.bloom.data(), t.bloom.size() * 4, (void **)&d->bloom)) != hipSuccess) return e;
+  if ((e = up(t.slots.data(), t.slots.size() * 4, (void **)&d->slots)) != hipSuccess) return e;
+  if ((e = up(t.pat40.data(), t.pat40.size() * 8, (void **)&d->pat40)) != hipSuccess) return e;
+  if ((e = up(t.pat_len.data(), t.pat_len.size(), (void **)&d->pat_len)) != hipSuccess) return e;
+  if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
+  if ((e = up(t.pat_codes.data(), t.pat_codes.size(), (void **)&d->pat_codes)) != hipSuccess) return e;
+  if ((e = up(t.cmap, 256, (void **)&d->cmap)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_seed_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SEED_LDS_BYTES)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+
+void seed_free(SeedDevice *d) {
+  void *ptrs[] = {d->bloom, d->slots, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  *d = SeedDevice();
+}
+
+ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end) {
+  ScanGeometry g;
+  int64_t chunk = 1 << 19;                                         // 512 KiB per workgroup
+  if (const char *env = getenv("PM_SEED_CHUNK")) {                 // test knob
+    const int64_t v = atoll(env);
+    if (v >= 1024 * WAVES) chunk = v / (1024 * WAVES) * (1024 * WAVES);
+  }
+  g.seg_len = chunk;
+  const int64_t c_lo = begin / chunk, c_hi = end > begin ? (end - 1) / chunk : c_lo - 1;
+  g.nseg = (int)(c_hi - c_lo + 1);
+  g.threads = SEED_THREADS;
+  g.blocks = g.nseg * d.ncombos;
+  return g;
+}
+
+hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
+                       pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
+                       ScanGeometry *geo_out) {
+  if (end > n) end = n;
+  ScanGeometry g = seed_geometry(d, begin, end);
+  if (geo_out) *geo_out = g;
+  if (g.blocks <= 0 || d.nslots == 0) return hipSuccess;
+  SeedArgs a;
+  a.text = d_text; a.n = n; a.begin = begin; a.end = end;
+  a.chunk_len = g.seg_len; a.chunk0 = begin / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
+  a.group = 256;                                                   // one run ~ one chunk per CU
+  if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
+  a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
+  memcpy(a.piece_shift, d.piece_shift, sizeof(a.piece_shift));
+  a.pmask = (1u << (2 * d.pb)) - 1u;
+  a.bloom = d.bloom; a.slots = reinterpret_cast<const uint2 *>(d.slots); a.slot_mask = (uint32_t)(d.nslots - 1);
+  a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
+  a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
+  hipLaunchKernelGGL(pm_seed_scan, dim3(g.blocks), dim3(SEED_THREADS), SEED_LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace pm

@@ -18,7 +18,8 @@ CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.json")) if "config1" n
 SEL2SEM = {0: sat_amd.SEM_AUTO, 1: sat_amd.SEM_KEYWORD_TREE, 2: sat_amd.SEM_KEYWORD_TREE, 4: sat_amd.SEM_SHIFT_AND,
            5: sat_amd.SEM_FILTER_BITVEC, 12: sat_amd.SEM_EXACT_HALVES, 14: sat_amd.SEM_EXACT_HALVES,
            100: sat_amd.SEM_SHIFT_AND_INEXACT}
-KERNELS = [sat_amd.KERNEL_BITPAR]
+KERNELS = [sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED, sat_amd.KERNEL_AUTO]
+SEED_OK = lambda sem, k, indels: (k == 0 or not indels) and sem != sat_amd.SEM_EXACT_BASES
 
 
 def gpu_hits(codes, table, patterns, sem, k, indels, kernel=sat_amd.KERNEL_BITPAR, chunk=1 << 26, esb=None, eeb=None):
@@ -53,14 +54,24 @@ def test_config1_known_answer():
 def test_golden_engine_hits(path, kernel, monkeypatch):
     monkeypatch.setenv("PM_BITPAR_SEGLEN", "512")      # many segments: exercises halo + ownership
     c, codes, table, allp = load(path)
+    monkeypatch.setenv("PM_SEED_CHUNK", "16384")
+    monkeypatch.setenv("PM_SEED_GROUP", "3")
+    ran = 0
     for name, e in c["engine"].items():
+        if kernel == sat_amd.KERNEL_SEED and not SEED_OK(SEL2SEM[e["sel"]], e["k"], e["indels"]):
+            continue
         got = gpu_hits(codes, table, allp, SEL2SEM[e["sel"]], e["k"], e["indels"], kernel)
-        assert got == [tuple(h) for h in e["hits"]], (c["name"], name)
+        assert got == [tuple(h) for h in e["hits"]], (c["name"], name, kernel)
+        ran += 1
+    assert ran >= 8
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_random_vs_oracle(seed, monkeypatch):
+@pytest.mark.parametrize("kernel", [sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_AUTO])
+def test_random_vs_oracle(seed, kernel, monkeypatch):
     monkeypatch.setenv("PM_BITPAR_SEGLEN", str([256, 768, 4096][seed % 3]))
+    monkeypatch.setenv("PM_SEED_CHUNK", str([16384, 32768, 1 << 19][seed % 3]))
+    monkeypatch.setenv("PM_SEED_GROUP", str([1, 2, 256][seed % 3]))
     rng = np.random.default_rng(77 + seed)
     ents = synth.make_entries(rng, int(rng.integers(1, 5)), int(rng.integers(300, 3000)), n_runs=int(rng.integers(0, 4)),
                               repeats=(seed % 2 == 0), short=(seed % 3 == 0))
@@ -80,18 +91,20 @@ def test_random_vs_oracle(seed, monkeypatch):
                                   (sat_amd.SEM_FILTER_BITVEC, 5, 1, True), (sat_amd.SEM_EXACT_HALVES, 12, 2, True)]:
             eng = O.pick_engine(text, allp, k, ind) if osel == 0 else osel
             want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=ind))
-            got = gpu_hits(data, tb, allp, sem, k, ind)
-            assert got == want, (seed, norm, sem, k, ind, len(want), len(got))
+            got = gpu_hits(data, tb, allp, sem, k, ind, kernel)
+            assert got == want, (seed, norm, sem, k, ind, kernel, len(want), len(got))
 
 
 def test_chunked_scan_equals_whole(monkeypatch):
     """find_patterns is resumable: small pm_scan ranges give the same hit set,
     including clusters and seeds that straddle range boundaries."""
     c, codes, table, allp = load(CASES[-1])
-    for sem, k, ind in [(sat_amd.SEM_AUTO, 0, True), (sat_amd.SEM_AUTO, 1, True), (sat_amd.SEM_AUTO, 2, True), (sat_amd.SEM_AUTO, 2, False)]:
-        whole = gpu_hits(codes, table, allp, sem, k, ind)
-        for chunk in (97, 1000, 4096):
-            assert gpu_hits(codes, table, allp, sem, k, ind, chunk=chunk) == whole, (sem, k, ind, chunk)
+    for sem, k, ind in [(sat_amd.SEM_AUTO, 0, True), (sat_amd.SEM_AUTO, 1, True), (sat_amd.SEM_AUTO, 1, False),
+                        (sat_amd.SEM_AUTO, 2, True), (sat_amd.SEM_AUTO, 2, False)]:
+        for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_AUTO):
+            whole = gpu_hits(codes, table, allp, sem, k, ind, kernel)
+            for chunk in (97, 1000, 4096):
+                assert gpu_hits(codes, table, allp, sem, k, ind, kernel, chunk=chunk) == whole, (sem, k, ind, kernel, chunk)
 
 
 def test_sharded_candidates_then_finalize():
@@ -99,7 +112,7 @@ def test_sharded_candidates_then_finalize():
     then one pm_finalize == single scan."""
     c, codes, table, allp = load(CASES[0])
     n = codes.size
-    for k, ind in [(0, True), (1, True), (2, False), (2, True)]:
+    for k, ind in [(0, True), (1, True), (1, False), (2, False), (2, True)]:
         pm = sat_amd.PatternMatch(k=k, indels=ind)
         for i, p in enumerate(allp):
             pm.add_pattern(p, i + 1)
@@ -126,7 +139,8 @@ def test_edge_cases():
         sem = sat_amd.SEM_SHIFT_AND_INEXACT if eng == 100 else sat_amd.SEM_AUTO
         text = O.Text(enc(s), table)
         want = O.sorted_tuples(O.find_all(text, [pat, pat[2:] + "AC"], engine=eng, k=k, indels=ind))
-        assert gpu_hits(enc(s), table, [pat, pat[2:] + "AC"], sem, k, ind) == want, (k, ind, eng)
+        for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_AUTO):
+            assert gpu_hits(enc(s), table, [pat, pat[2:] + "AC"], sem, k, ind, kernel) == want, (k, ind, eng, kernel)
 
 
 def test_candidate_overflow_is_reported_and_recovered():
