@@ -227,6 +227,7 @@ def main():
         if rank == 0:
             cand_count[0] = cands.size
             if world == 1:
+                pm.reset()
                 hits = pm.finalize(cands, end, last=True)
             else:
                 hits = finalize_global(cands)

@@ -34,7 +34,7 @@ struct SeedDevice {
   uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr;
   void *pat40 = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr;
-  uint32_t piece_shift[SEED_MAX_COMBOS][4] = {};
+  uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {};
   int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;
   bool ascii = false;
   size_t nslots = 0;

@@ -35,9 +35,10 @@ namespace pm {
 
 namespace {
 
-constexpr int QCAP = SEED_QCAP;                // queue entries per wave (8 B each)
-constexpr int WAVES = SEED_THREADS / 64;  // 8
+constexpr int QCAP = SEED_QCAP;           // queue entries per wave (8 B each)
+constexpr int WAVES = SEED_THREADS / 64;
 constexpr uint32_t EMPTY = 0xffffffffu;
+constexpr uint32_t HASH_LO = 0x9E3779B1u, HASH_HI = 0x9E3779u, HASH_SLOT = 0x85EBCA6Bu;
 
 struct SeedArgs {
   const uint8_t *text;
@@ -46,16 +47,16 @@ struct SeedArgs {
   int64_t chunk_len;                    // bytes per workgroup, multiple of 1024*WAVES
   int nchunks, ncombos, group;          // group = chunks per (superchunk, combo) run
   int k, Lw, pb, r, ascii;
-  uint32_t piece_shift[SEED_MAX_COMBOS][4];   // bit offset of each piece of a combo inside the window
-  uint32_t pmask;                       // (1 << 2*pb) - 1
+  uint32_t mask_lo[SEED_MAX_COMBOS];    // window bits (2 per base) that belong to the combo's pieces
+  uint32_t mask_hi[SEED_MAX_COMBOS];
   const uint32_t *bloom;                // [combo][SEED_BLOOM_WORDS]
-  const uint2 *slots;                   // [combo][nslots]  {key, pattern index}
+  const uint2 *slots;                   // [combo][nslots]  {window hash, pattern index}
   uint32_t slot_mask;
   const uint2 *pat40;                   // packed last Lw bases of every pattern
   const uint8_t *pat_len;
   const uint32_t *pat_id;
   const uint8_t *pat_codes;             // stream codes of every pattern char, 32 bytes per pattern
-  const uint8_t *cmap;                  // stream code -> 0 ok, 1 EOS (anything else is just a code)
+  const uint8_t *cmap;                  // stream code -> 1 for EOS, else 0
   pm_hit *out;
   unsigned long long *counter;
   unsigned long long cap;
@@ -72,43 +73,42 @@ __device__ __forceinline__ uint32_t pack16(const uint4 &v, int sh) {
   return pack4(v.x, sh) | (pack4(v.y, sh) << 8) | (pack4(v.z, sh) << 16) | (pack4(v.w, sh) << 24);
 }
 
-__device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_t n) {
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (off >= 0 && off + 16 <= n) v = *reinterpret_cast<const uint4 *>(text + off);
-  else {
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (int b = 0; b < 16; ++b) {
-      const int64_t p = off + b;
-      if (p >= 0 && p < n) w[b >> 2] |= (uint32_t)text[p] << (8 * (b & 3));
-    }
-    v = make_uint4(w[0], w[1], w[2], w[3]);
+__device__ __noinline__ uint4 load16_edge(const uint8_t *text, int64_t off, int64_t n) {
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (int b = 0; b < 16; ++b) {
+    const int64_t p = off + b;
+    if (p >= 0 && p < n) w[b >> 2] |= (uint32_t)text[p] << (8 * (b & 3));
   }
-  return v;
+  return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__device__ __forceinline__ uint32_t combo_key(uint32_t wlo, uint32_t whi, const SeedArgs &a, int combo) {
-  const uint64_t W = ((uint64_t)whi << 32) | wlo;
-  uint32_t key = 0;
-  for (int t = 0; t < a.r; ++t)
-    key |= ((uint32_t)(W >> a.piece_shift[combo][t]) & a.pmask) << (2 * a.pb * t);
-  return key;
+__device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_t n) {
+  if (off >= 0 && off + 16 <= n) return *reinterpret_cast<const uint4 *>(text + off);
+  return load16_edge(text, off, n);
 }
 
-__device__ __forceinline__ uint32_t bloom_mask(uint32_t h) {
+// hash of the combo-masked window: Bloom word/bits and slot index are all cut from it
+__device__ __host__ __forceinline__ uint32_t window_hash(uint32_t wlo, uint32_t whi, uint32_t mlo, uint32_t mhi) {
+  uint32_t x = (wlo & mlo) + (whi & mhi) * HASH_HI;     // fold, then one multiplicative round:
+  x ^= x >> 16;                                          // every selector below comes out of bits
+  return x * HASH_LO;                                    // that saw both halves of the key
+}
+
+__device__ __forceinline__ uint32_t bloom_bits(uint32_t h) {
   return (1u << ((h >> 12) & 31)) | (1u << ((h >> 7) & 31)) | (1u << ((h >> 2) & 31));
 }
 
 // Second and third stage for one queued window.
-__device__ __forceinline__ void verify_entry(const SeedArgs &a, int combo, uint32_t wlo, uint32_t whi, int64_t p) {
-  const uint32_t key = combo_key(wlo, whi, a, combo);
-  const uint2 *slots = a.slots + (size_t)combo * (a.slot_mask + 1);
-  uint32_t idx = (key * 0x85EBCA6Bu) >> 7 & a.slot_mask;
+__device__ __forceinline__ void verify_entry(const SeedArgs &a, const uint2 *slots, uint32_t mlo, uint32_t mhi,
+                                             uint32_t wlo, uint32_t whi, int64_t p) {
+  const uint32_t h = window_hash(wlo, whi, mlo, mhi);
+  uint32_t idx = ((h * HASH_SLOT) >> 7) & a.slot_mask;
   const uint64_t W = ((uint64_t)whi << 32) | wlo;
   for (;;) {
     const uint2 s = slots[idx];
     if (s.y == EMPTY) break;
     idx = (idx + 1) & a.slot_mask;
-    if (s.x != key) continue;
+    if (s.x != h) continue;
     const uint32_t pi = s.y;
     const uint2 pp = a.pat40[pi];
     const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
@@ -122,6 +122,7 @@ __device__ __forceinline__ void verify_entry(const SeedArgs &a, int combo, uint3
     int ham = 0;
     uint32_t dirty = 0;                               // pieces (of the last Lw bases) with a mismatch
     bool left_clean = true, right_clean = true, dead = false;
+    const int m = a.k + a.r;
     for (int i = 0; i < L; ++i) {
       const uint8_t tc = a.text[start + i];
       if (a.cmap[tc] == 1) { dead = true; break; }    // EOS inside the window: never a candidate
@@ -129,32 +130,28 @@ __device__ __forceinline__ void verify_entry(const SeedArgs &a, int combo, uint3
         if (++ham > a.k) { dead = true; break; }
         if (i < L / 2) left_clean = false; else right_clean = false;
         const int j = i - (L - a.Lw);                 // position inside the seeded suffix
-        if (j >= 0 && j / a.pb < a.k + a.r) dirty |= 1u << (j / a.pb);
+        if (j >= 0 && j / a.pb < m) dirty |= 1u << (j / a.pb);
       }
     }
     if (dead) continue;
     // report once: only through the combo made of the first r clean pieces
-    bool mine = true;
-    {
-      int t = 0;
-      const int m = a.k + a.r;
-      for (int j = 0; j < m && t < a.r; ++j) {
-        if (dirty >> j & 1) continue;
-        if (a.piece_shift[combo][t] != (uint32_t)(2 * a.pb * j)) { mine = false; break; }
-        ++t;
-      }
-    }
-    if (!mine) continue;
+    uint64_t first = 0;
+    const uint64_t field = (1ull << (2 * a.pb)) - 1ull;
+    for (int j = 0, t = 0; j < m && t < a.r; ++j)
+      if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
+    if (first != (((uint64_t)mhi << 32) | mlo)) continue;
     const unsigned long long o = atomicAdd(a.counter, 1ull);
     if (o < a.cap) {
-      pm_hit h;
-      h.end = p + 1; h.pid = a.pat_id[pi]; h.k = (uint8_t)ham;
-      h.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); h.aux[1] = h.aux[2] = 0;
-      a.out[o] = h;
+      pm_hit hh;
+      hh.end = p + 1; hh.pid = a.pat_id[pi]; hh.k = (uint8_t)ham;
+      hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
+      a.out[o] = hh;
     }
   }
 }
 
+// LW > 0: window length known at compile time (all shifts immediate); LW == 0: taken from a.Lw.
+template <int LW>
 __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   uint32_t *bloom = lds;                                          // SEED_BLOOM_WORDS dwords
@@ -193,9 +190,12 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   int64_t own_hi = ws + sub;
   if (own_hi > a.end) own_hi = a.end;
   if (own_hi > a.n) own_hi = a.n;
-  if (own_lo < a.Lw - 1) own_lo = a.Lw - 1;                       // the window must fit in the stream
+  const int Lw = LW > 0 ? LW : a.Lw;
+  if (own_lo < Lw - 1) own_lo = Lw - 1;                           // the window must fit in the stream
   if (own_lo >= own_hi) return;
 
+  const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo];
+  const uint2 *slots = a.slots + (size_t)combo * (a.slot_mask + 1);
   const int sh = a.ascii ? 1 : 0;
   // the 32 bases in front of the wave's range
   uint32_t carry1, carry2;
@@ -205,55 +205,96 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     carry2 = __builtin_amdgcn_readlane(pk, 0);
     carry1 = __builtin_amdgcn_readlane(pk, 1);
   }
-  const int wbits = 2 * a.Lw;
+  const int wbits = 2 * Lw;
   const uint32_t lo_mask = wbits >= 32 ? 0xffffffffu : ((1u << wbits) - 1u);
   const uint32_t hi_mask = wbits > 32 ? ((1u << (wbits - 32)) - 1u) : 0u;
   int qn = 0;                                                     // wave-uniform queue fill
 
+  // window whose last base is base i of this lane's 16: bits [s, s+2Lw) of prev2:prev1:cur
+  auto window = [&](int i, uint32_t prev2, uint32_t prev1, uint32_t cur, uint32_t &wlo, uint32_t &whi) {
+    const int s = 2 * (i - Lw + 33);
+    if (s < 32) { wlo = __builtin_amdgcn_alignbit(prev1, prev2, s); whi = __builtin_amdgcn_alignbit(cur, prev1, s); }
+    else if (s < 64) { wlo = __builtin_amdgcn_alignbit(cur, prev1, s - 32); whi = cur >> (s - 32); }
+    else { wlo = cur >> (s - 64); whi = 0; }
+    wlo &= lo_mask; whi &= hi_mask;
+  };
+  auto drain = [&]() {
+    for (int q = lane; q < qn; q += 64) {
+      const uint2 e = queue[q];
+      verify_entry(a, slots, mlo, mhi, e.x, e.y & 0xffu, ws + (e.y >> 8));
+    }
+    qn = 0;
+  };
+
+  uint4 vnext = load16(a.text, ws + 16 * lane, a.n);
   for (int64_t bb = ws; bb < own_hi; bb += 1024) {
-    const uint4 v = load16(a.text, bb + 16 * lane, a.n);
+    const uint4 v = vnext;
+    if (bb + 1024 < own_hi) vnext = load16(a.text, bb + 1024 + 16 * lane, a.n);   // next block in flight
     const uint32_t cur = pack16(v, sh);
     uint32_t prev1 = __shfl_up(cur, 1), prev2 = __shfl_up(cur, 2);
     if (lane == 0) { prev1 = carry1; prev2 = carry2; }
     if (lane == 1) prev2 = carry1;
     carry2 = __builtin_amdgcn_readlane(cur, 62);
     carry1 = __builtin_amdgcn_readlane(cur, 63);
-    const uint64_t A = ((uint64_t)prev1 << 32) | prev2, B = ((uint64_t)cur << 32) | prev1;
     const int64_t pbase = bb + 16 * lane;
-    const bool last_block = bb + 1024 >= own_hi;
-    int i = 0;
-    for (;;) {
-      // first stage: 64 windows per step, until the queue could overflow
-      for (; i < 16 && qn + 64 <= QCAP; ++i) {
-        const int s = 2 * (i - a.Lw + 33);                         // bit offset of the window in prev2:prev1:cur
-        uint32_t wlo, whi;
-        if (s < 32) { wlo = (uint32_t)(A >> s); whi = (uint32_t)(B >> s); }
-        else { wlo = (uint32_t)(B >> (s - 32)); whi = cur >> (s - 32); }
-        wlo &= lo_mask; whi &= hi_mask;
-        const uint32_t key = combo_key(wlo, whi, a, combo);
-        const uint32_t h = key * 0x9E3779B1u;
-        const uint32_t word = bloom[h >> 17];
-        const uint32_t bm = bloom_mask(h);
-        const int64_t p = pbase + i;
-        const bool pass = ((word & bm) == bm) && p >= own_lo && p < own_hi;
+    // positions of this lane that this wave owns (all 16 except in the first/last block)
+    uint32_t own;
+    {
+      const int64_t lo = own_lo - pbase, hi = own_hi - pbase;
+      const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
+      own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
+    }
+    // first stage, part 1: 16 hashes, 16 LDS reads in flight
+    uint32_t wl[16], hs[16], wd[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint32_t whi;
+      window(i, prev2, prev1, cur, wl[i], whi);
+      hs[i] = window_hash(wl[i], whi, mlo, mhi);
+      wd[i] = bloom[hs[i] >> 17];
+    }
+    // part 2: tests -> per-lane survivor bits and the wave total
+    uint32_t pbits = 0;
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t bm = bloom_bits(hs[i]);
+      const bool pass = ((wd[i] & bm) == bm) && (own >> i & 1u);
+      total += __popcll(__ballot(pass));
+      pbits |= pass ? (1u << i) : 0u;
+    }
+    if (qn + total > QCAP) drain();                               // second stage on full waves of survivors
+    if (total <= QCAP) {
+      // part 3: ballot + mbcnt compaction into the wave's queue
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool pass = pbits >> i & 1u;
         const unsigned long long bal = __ballot(pass);
         if (pass) {
+          uint32_t wlo, whi;
+          window(i, prev2, prev1, cur, wlo, whi);
           const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-          queue[slot] = make_uint2(wlo, whi | ((uint32_t)(p - ws) << 8));
+          queue[slot] = make_uint2(wlo, whi | ((uint32_t)(pbase + i - ws) << 8));
         }
         qn += __popcll(bal);
       }
-      // second stage on full waves of survivors (single call site: the body is large)
-      if (qn + 64 > QCAP || (i == 16 && last_block)) {
-        for (int q = lane; q < qn; q += 64) {
-          const uint2 e = queue[q];
-          verify_entry(a, combo, e.x, e.y & 0xffu, ws + (e.y >> 8));
+    } else {
+      // a block with more survivors than the queue holds (low-complexity stream): step by step
+      for (int i = 0; i < 16; ++i) {
+        if (qn + 64 > QCAP) drain();
+        const bool pass = pbits >> i & 1u;
+        const unsigned long long bal = __ballot(pass);
+        if (pass) {
+          uint32_t wlo, whi;
+          window(i, prev2, prev1, cur, wlo, whi);
+          const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+          queue[slot] = make_uint2(wlo, whi | ((uint32_t)(pbase + i - ws) << 8));
         }
-        qn = 0;
+        qn += __popcll(bal);
       }
-      if (i == 16) break;
     }
   }
+  drain();
 }
 
 }  // namespace
@@ -295,8 +336,8 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   double best = 1e300;
   const double P = std::max<size_t>(pats.size(), 1);
   for (int r = 1; r <= 4; ++r) {
-    const int m = k + r, pb = t.Lw / m;
-    if (pb < 1 || r * pb > 16 || m > 8) continue;
+    const int m = k + r, pb = std::min(t.Lw / m, 16 / r);
+    if (pb < 1 || m > 8) continue;
     const double C = (double)binom(m, r);
     if (C > SEED_MAX_COMBOS) continue;
     double keys = 1; for (int i = 0; i < r * pb; ++i) keys *= 4;
@@ -328,7 +369,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.slots.assign((size_t)C * nslots * 2, EMPTY);
   for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
   if (eos_code >= 0 && eos_code < 256) t.cmap[eos_code] = 1;
-  const uint32_t pmask = (1u << (2 * t.pb)) - 1u;
+  const uint64_t pmask = (1ull << (2 * t.pb)) - 1ull;
   for (size_t j = 0; j < np; ++j) {
     const std::string &s = pats[j].s;
     const int L = (int)s.size();
@@ -339,14 +380,14 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
     t.pat_id[j] = ids[j];
     for (int i = 0; i < L; ++i) t.pat_codes[j * 32 + i] = (uint8_t)alpha.nch[(unsigned char)s[i]];
     for (int ci = 0; ci < C; ++ci) {
-      uint32_t key = 0;
-      for (int q = 0; q < t.r; ++q) key |= ((uint32_t)(w >> (2 * t.pb * t.combos[ci][q])) & pmask) << (2 * t.pb * q);
-      const uint32_t h = key * 0x9E3779B1u;
+      uint64_t cm = 0;
+      for (int q = 0; q < t.r; ++q) cm |= pmask << (2 * t.pb * t.combos[ci][q]);
+      const uint32_t h = window_hash((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)cm, (uint32_t)(cm >> 32));
       t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h >> 17)] |= (1u << ((h >> 12) & 31)) | (1u << ((h >> 7) & 31)) | (1u << ((h >> 2) & 31));
-      uint32_t idx = ((key * 0x85EBCA6Bu) >> 7) & (uint32_t)(nslots - 1);
+      uint32_t idx = ((h * HASH_SLOT) >> 7) & (uint32_t)(nslots - 1);
       uint32_t *sl = &t.slots[(size_t)ci * nslots * 2];
       while (sl[2 * idx + 1] != EMPTY) idx = (idx + 1) & (uint32_t)(nslots - 1);
-      sl[2 * idx] = key; sl[2 * idx + 1] = (uint32_t)j;
+      sl[2 * idx] = h; sl[2 * idx + 1] = (uint32_t)j;
     }
   }
   return "";
@@ -356,8 +397,11 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   seed_free(d);
   d->k = t.k; d->Lw = t.Lw; d->pb = t.pb; d->r = t.r; d->ascii = t.ascii; d->maxlen = t.maxlen;
   d->ncombos = (int)t.combos.size(); d->nslots = t.nslots;
-  for (int c = 0; c < d->ncombos; ++c)
-    for (int q = 0; q < 4; ++q) d->piece_shift[c][q] = (uint32_t)(2 * t.pb * t.combos[c][q]);
+  for (int c = 0; c < d->ncombos; ++c) {
+    uint64_t cm = 0;
+    for (int q = 0; q < t.r; ++q) cm |= ((1ull << (2 * t.pb)) - 1ull) << (2 * t.pb * t.combos[c][q]);
+    d->mask_lo[c] = (uint32_t)cm; d->mask_hi[c] = (uint32_t)(cm >> 32);
+  }
   auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
     if (e != hipSuccess) return e;
@@ -371,7 +415,9 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
   if ((e = up(t.pat_codes.data(), t.pat_codes.size(), (void **)&d->pat_codes)) != hipSuccess) return e;
   if ((e = up(t.cmap, 256, (void **)&d->cmap)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_seed_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_seed_scan<20>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SEED_LDS_BYTES)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_seed_scan<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                SEED_LDS_BYTES)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
 }
@@ -410,12 +456,13 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   a.group = 256;                                                   // one run ~ one chunk per CU
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
-  memcpy(a.piece_shift, d.piece_shift, sizeof(a.piece_shift));
-  a.pmask = (1u << (2 * d.pb)) - 1u;
+  memcpy(a.mask_lo, d.mask_lo, sizeof(a.mask_lo));
+  memcpy(a.mask_hi, d.mask_hi, sizeof(a.mask_hi));
   a.bloom = d.bloom; a.slots = reinterpret_cast<const uint2 *>(d.slots); a.slot_mask = (uint32_t)(d.nslots - 1);
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
-  hipLaunchKernelGGL(pm_seed_scan, dim3(g.blocks), dim3(SEED_THREADS), SEED_LDS_BYTES, st, a);
+  if (d.Lw == 20) hipLaunchKernelGGL(pm_seed_scan<20>, dim3(g.blocks), dim3(SEED_THREADS), SEED_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(pm_seed_scan<0>, dim3(g.blocks), dim3(SEED_THREADS), SEED_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 
