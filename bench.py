@@ -228,7 +228,7 @@ def main():
             cand_count[0] = cands.size
             if world == 1:
                 pm.reset()
-                hits = pm.finalize(cands, end, last=True)
+                hits = pm.finalize(cands, end, last=True, sort=False)
             else:
                 hits = finalize_global(cands)
             final_hits[0] = hits.size
@@ -242,7 +242,7 @@ def main():
             raise SystemExit("bench.py --gpus>1: this option set needs stream text in the verify stage; "
                              "supported multi-GPU runs are k=0 and -K k (see DESIGN.md)")
         pm.reset()
-        return pm.finalize(cands, int(cands["end"].max()) + 1 if cands.size else 0, last=True)
+        return pm.finalize(cands, int(cands["end"].max()) + 1 if cands.size else 0, last=True, sort=False)
 
     for _ in range(args.warmup):
         step()

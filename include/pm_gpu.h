@@ -126,9 +126,13 @@ int pm_set_capacity(pm_handle *h, size_t max_candidates);
 
 /* Host stage: cluster / dedup / verify candidate records that arrive in any order within a
  * batch but batch-wise in increasing stream order (filter_bitvec.cc:88-177,
- * exact_halves.cc:140-190).  `last` != 0 flushes deferred clusters.  Needs the text: either the
- * host pointer given to pm_init or, for pm_init_device, windows fetched from HBM. */
-int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int last,
+ * exact_halves.cc:140-190).  flags: PM_FINALIZE_LAST flushes deferred clusters (no more input),
+ * PM_FINALIZE_SORTED orders the output by (end,pid) (otherwise unspecified, like the emission
+ * order of the reference engines).  Text, where the verify needs it, comes from the host pointer
+ * given to pm_init or, for pm_init_device, from windows fetched out of HBM. */
+#define PM_FINALIZE_LAST 1
+#define PM_FINALIZE_SORTED 2
+int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int flags,
                 pm_hit *out, size_t cap, size_t *n_out);
 
 /* PatternMatch::reset (pattern_match.h:134): forget scan state, keep patterns and text. */

@@ -514,66 +514,79 @@ pm_hit make_hit(int64_t end, uint64_t pid, int k) {
 }
 
 // filter_bitvec::find_patterns (filter_bitvec.cc:88-177) over carried + new candidates.
+// The reference sorts all candidates by position and, for every still-live candidate, chains
+// later candidates of the same pattern while they lie within 2k+1 of the last one chained
+// (:103-116).  Chains never mix patterns, so the same clusters fall out of grouping the
+// candidates by pattern (counting sort, O(n)) and cutting each pattern's ends at gaps > 2k+1.
 int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
                            std::vector<pm_hit> &outv) {
-  std::vector<pm_hit> &l = h->carry;
-  l.insert(l.end(), cands, cands + n);
-  std::stable_sort(l.begin(), l.end(), by_end_pid);                 // l.normalize() (:92)
+  const size_t np = h->pats.size();
   const int k = h->cfg.k, win = 2 * k + 1;
   const bool indels = h->cfg.indels != 0;
-  struct Cluster { int64_t first, last; uint32_t pid; int best_lvl; int64_t best_end; };
-  std::vector<Cluster> clusters;
-  std::vector<char> used(l.size(), 0);
-  size_t stop = l.size();
-  for (size_t i = 0; i < l.size(); ++i) {
-    if (used[i]) continue;
-    Cluster c{l[i].end, l[i].end, l[i].pid, l[i].k, l[i].end};
-    std::vector<size_t> members{i};
-    for (size_t j = i + 1; j < l.size() && (used[j] || l[j].end <= c.last + win); ++j) {   // :103-116
-      if (used[j] || l[j].pid != c.pid) continue;
-      c.last = l[j].end;
-      if (l[j].k < c.best_lvl) { c.best_lvl = l[j].k; c.best_end = l[j].end; }
-      members.push_back(j);
-    }
-    if (!last && scanned_to < c.last + win) { stop = i; break; }    // :118-121: cluster may still grow
-    for (size_t m : members) used[m] = 1;
-    clusters.push_back(c);
+  const size_t total = h->carry.size() + n;
+  if (total == 0) return PM_OK;
+  // group by inner pattern id (1..np)
+  std::vector<uint32_t> first(np + 2, 0);
+  for (const pm_hit &c : h->carry) ++first[c.pid + 1];
+  for (size_t i = 0; i < n; ++i) ++first[cands[i].pid + 1];
+  for (size_t j = 1; j <= np + 1; ++j) first[j] += first[j - 1];
+  std::vector<pm_hit> g(total);
+  {
+    std::vector<uint32_t> at(first.begin(), first.end() - 1);
+    for (const pm_hit &c : h->carry) g[at[c.pid]++] = c;
+    for (size_t i = 0; i < n; ++i) g[at[cands[i].pid]++] = cands[i];
   }
-  // Verify.  Substitution-only search without exact-base constraints needs no text: the DP
-  // (pattern_alignment.cc, b = 0) walks diagonals only, so the cluster's value is the smallest
-  // Hamming distance among its windows -- which is the smallest candidate level, windows that
-  // are not candidates having distance > k -- and the column rule (:461-475) keeps the
-  // left-most such window.
-  std::vector<Window> wins;
-  std::vector<size_t> need_dp;
-  for (size_t ci = 0; ci < clusters.size(); ++ci) {
-    const Cluster &c = clusters[ci];
-    const Pattern &p = h->pats[c.pid - 1];
-    if (!indels && p.esb == 0 && p.eeb == 0) {
-      outv.push_back(make_hit(c.best_end, p.id, c.best_lvl));
-    } else {
-      const int L = (int)p.s.size();
-      int64_t ws = 0;
-      if (c.first > (int64_t)L + k) ws = c.first - L - k;           // pattern_alignment.cc:137-139
-      wins.push_back(Window{ws, (int32_t)(c.last - ws), 0});
-      need_dp.push_back(ci);
+  std::vector<pm_hit> keep;
+  struct Cluster { int64_t first, last; uint32_t pid; };
+  std::vector<Cluster> need_dp;
+  for (size_t pid = 1; pid <= np; ++pid) {
+    const size_t lo = first[pid], hi = first[pid + 1];
+    if (lo == hi) continue;
+    if (hi - lo > 1) std::sort(g.begin() + lo, g.begin() + hi, [](const pm_hit &a, const pm_hit &b) { return a.end < b.end; });
+    const Pattern &p = h->pats[pid - 1];
+    const int L = (int)p.s.size();
+    size_t i = lo;
+    while (i < hi) {
+      size_t j = i + 1;
+      int best_lvl = g[i].k; int64_t best_end = g[i].end;
+      while (j < hi && g[j].end <= g[j - 1].end + win) {
+        if (g[j].k < best_lvl) { best_lvl = g[j].k; best_end = g[j].end; }
+        ++j;
+      }
+      const int64_t c_first = g[i].end, c_last = g[j - 1].end;
+      if (!last && scanned_to < c_last + win) {                     // :118-121: the cluster may still grow
+        keep.insert(keep.end(), g.begin() + i, g.begin() + j);
+      } else if (!indels && p.esb == 0 && p.eeb == 0 && c_first >= L) {
+        // Substitution-only search without exact-base constraints needs no text: the DP
+        // (pattern_alignment.cc with b = 0) walks diagonals only, so the cluster's value is the
+        // smallest Hamming distance among its windows -- the smallest candidate level, windows that
+        // are not candidates having distance > k -- and the column rule (:461-475) keeps the
+        // left-most such window.
+        outv.push_back(make_hit(best_end, p.id, best_lvl));
+      } else need_dp.push_back(Cluster{c_first, c_last, (uint32_t)pid});
+      i = j;
     }
+  }
+  h->carry.swap(keep);
+  if (need_dp.empty()) return PM_OK;
+  std::vector<Window> wins;
+  wins.reserve(need_dp.size());
+  for (const Cluster &c : need_dp) {
+    const int L = (int)h->pats[c.pid - 1].s.size();
+    int64_t ws = 0;
+    if (c.first > (int64_t)L + k) ws = c.first - L - k;             // pattern_alignment.cc:137-139
+    wins.push_back(Window{ws, (int32_t)(c.last - ws), 0});
   }
   int rc = fetch_windows(h, wins);
   if (rc) return rc;
   AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
   for (size_t wi = 0; wi < need_dp.size(); ++wi) {
-    const Cluster &c = clusters[need_dp[wi]];
+    const Cluster &c = need_dp[wi];
     const Pattern &p = h->pats[c.pid - 1];
     AlignResult r = editdist_align(h->winbuf.data() + wins[wi].off, wins[wi].start, c.first, c.last,
                                    p.s.data(), (int)p.s.size(), p.esb, p.eeb, prm, h->scratch);
     if (r.ok) outv.push_back(make_hit(r.end, p.id, r.value));       // :135
   }
-  // keep what was not consumed (:137-170)
-  std::vector<pm_hit> rest;
-  for (size_t i = 0; i < l.size(); ++i) if (!used[i]) rest.push_back(l[i]);
-  (void)stop;
-  l.swap(rest);
   return PM_OK;
 }
 
@@ -688,14 +701,15 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
   return rc;
 }
 
-extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int last,
+extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int flags,
                            pm_hit *out, size_t cap, size_t *n_out) {
+  const int last = flags & PM_FINALIZE_LAST;
   if (!h || !h->inited || (!cands && n)) return fail(h, PM_E_INVALID, "pm_finalize: bad arguments");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   std::vector<pm_hit> outv;
   int rc = finalize_into(h, cands, n, scanned_to, last != 0, outv);
   if (rc) return rc;
-  std::sort(outv.begin(), outv.end(), by_end_pid);
+  if (flags & PM_FINALIZE_SORTED) std::sort(outv.begin(), outv.end(), by_end_pid);
   if (n_out) *n_out = outv.size();
   if (outv.size() > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize: out buffer too small");
   if (!outv.empty()) memcpy(out, outv.data(), outv.size() * sizeof(pm_hit));

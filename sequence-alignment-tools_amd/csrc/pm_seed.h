@@ -16,12 +16,14 @@ constexpr int SEED_MAX_COMBOS = 16;
 constexpr int SEED_LDS_BYTES = SEED_BLOOM_WORDS * 4 + (SEED_THREADS / 64) * SEED_QCAP * 8;   // filter + wave queues
 
 struct SeedTables {
-  int k = 0, Lw = 0, pb = 0, r = 0, maxlen = 0;
+  int k = 0, Lw = 0, pb = 0, r = 0, maxlen = 0, mode = 0;
   bool ascii = false;
-  std::vector<std::array<int, 4>> combos;         // piece indices of every combo
+  std::vector<std::array<int, 4>> combos;
+  std::vector<uint32_t> perm_sel;         // piece indices of every combo
   size_t nslots = 0;
+  int idx_bits = 0, bucket_shift = 0;
   std::vector<uint32_t> bloom;                    // [combo][SEED_BLOOM_WORDS]
-  std::vector<uint32_t> slots;                    // [combo][nslots][2]
+  std::vector<uint32_t> slots;                    // [combo][nbuckets][8]
   struct P40 { uint32_t lo, hi; };
   std::vector<P40> pat40;
   std::vector<uint8_t> pat_len;
@@ -34,10 +36,12 @@ struct SeedDevice {
   uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr;
   void *pat40 = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr;
-  uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {};
+  uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
+  int mode = 0;
   int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;
   bool ascii = false;
   size_t nslots = 0;
+  int idx_bits = 0, bucket_shift = 0;
 };
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,

@@ -46,12 +46,13 @@ struct SeedArgs {
   int64_t chunk0;                       // first chunk index (absolute, chunk_len aligned)
   int64_t chunk_len;                    // bytes per workgroup, multiple of 1024*WAVES
   int nchunks, ncombos, group;          // group = chunks per (superchunk, combo) run
-  int k, Lw, pb, r, ascii;
+  int k, Lw, pb, r, ascii, debug;
   uint32_t mask_lo[SEED_MAX_COMBOS];    // window bits (2 per base) that belong to the combo's pieces
   uint32_t mask_hi[SEED_MAX_COMBOS];
+  uint32_t perm_sel[SEED_MAX_COMBOS];   // byte-aligned plans (pb == 4): v_perm selector gathering the pieces
   const uint32_t *bloom;                // [combo][SEED_BLOOM_WORDS]
-  const uint2 *slots;                   // [combo][nslots]  {window hash, pattern index}
-  uint32_t slot_mask;
+  const uint4 *buckets;                 // [combo][nbuckets][2]: 8 slots of (fingerprint << idx_bits | pattern index)
+  uint32_t bucket_shift, idx_bits;      // bucket = h2 >> bucket_shift; nbuckets = 2^(32-bucket_shift)
   const uint2 *pat40;                   // packed last Lw bases of every pattern
   const uint8_t *pat_len;
   const uint32_t *pat_id;
@@ -87,71 +88,108 @@ __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_
   return load16_edge(text, off, n);
 }
 
-// hash of the combo-masked window: Bloom word/bits and slot index are all cut from it
-__device__ __host__ __forceinline__ uint32_t window_hash(uint32_t wlo, uint32_t whi, uint32_t mlo, uint32_t mhi) {
-  uint32_t x = (wlo & mlo) + (whi & mhi) * HASH_HI;     // fold, then one multiplicative round:
-  x ^= x >> 16;                                          // every selector below comes out of bits
-  return x * HASH_LO;                                    // that saw both halves of the key
-}
-
-__device__ __forceinline__ uint32_t bloom_bits(uint32_t h) {
-  return (1u << ((h >> 12) & 31)) | (1u << ((h >> 7) & 31)) | (1u << ((h >> 2) & 31));
-}
-
-// Second and third stage for one queued window.
-__device__ __forceinline__ void verify_entry(const SeedArgs &a, const uint2 *slots, uint32_t mlo, uint32_t mhi,
-                                             uint32_t wlo, uint32_t whi, int64_t p) {
-  const uint32_t h = window_hash(wlo, whi, mlo, mhi);
-  uint32_t idx = ((h * HASH_SLOT) >> 7) & a.slot_mask;
+// Hash of the combo's part of a window.  MODE 0: any piece layout (mask + fold + multiply);
+// MODE 1: 4-base pieces = bytes, three of them gathered by one v_perm, 24-bit multiply;
+// MODE 2: four byte pieces, 32-bit multiply.  The Bloom word comes from the low 15 bits, the
+// three bit selectors from bits 27.., 22.., 17.. (seed_build mirrors this on the host).
+template <int MODE>
+__device__ __host__ __forceinline__ uint32_t window_hash(uint32_t wlo, uint32_t whi, uint32_t mlo, uint32_t mhi, uint32_t sel) {
+  if (MODE == 0) {
+    uint32_t x = (wlo & mlo) + (whi & mhi) * HASH_HI;
+    x ^= x >> 16;
+    return x * HASH_LO;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t key = __builtin_amdgcn_perm(whi, wlo, sel);
+  if (MODE == 1) return __umul24(key, HASH_HI);
+  return key * HASH_LO;
+#else
+  uint32_t key = 0;
   const uint64_t W = ((uint64_t)whi << 32) | wlo;
-  for (;;) {
-    const uint2 s = slots[idx];
-    if (s.y == EMPTY) break;
-    idx = (idx + 1) & a.slot_mask;
-    if (s.x != h) continue;
-    const uint32_t pi = s.y;
-    const uint2 pp = a.pat40[pi];
-    const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
-    const uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ull;
-    if (__popcll(mm) > a.k) continue;                 // packed distance never exceeds the true one
-    // exact distance on the raw stream codes
-    const int L = a.pat_len[pi];
-    const int64_t start = p + 1 - L;
-    if (start < 0) continue;
-    const uint8_t *pc = a.pat_codes + (size_t)pi * 32;
-    int ham = 0;
-    uint32_t dirty = 0;                               // pieces (of the last Lw bases) with a mismatch
-    bool left_clean = true, right_clean = true, dead = false;
-    const int m = a.k + a.r;
-    for (int i = 0; i < L; ++i) {
-      const uint8_t tc = a.text[start + i];
-      if (a.cmap[tc] == 1) { dead = true; break; }    // EOS inside the window: never a candidate
-      if (tc != pc[i]) {
-        if (++ham > a.k) { dead = true; break; }
-        if (i < L / 2) left_clean = false; else right_clean = false;
-        const int j = i - (L - a.Lw);                 // position inside the seeded suffix
-        if (j >= 0 && j / a.pb < m) dirty |= 1u << (j / a.pb);
-      }
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t sb = (sel >> (8 * q)) & 0xffu;
+    if (sb < 8) key |= (uint32_t)((W >> (8 * sb)) & 0xffu) << (8 * q);
+  }
+  if (MODE == 1) return (uint32_t)((uint64_t)(key & 0xffffffu) * HASH_HI);
+  return key * HASH_LO;
+#endif
+}
+
+// 1 if all three selected bits of the Bloom word are set (shift amounts use their low 5 bits)
+__device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h) {
+  return (word >> ((h >> 27) & 31)) & (word >> ((h >> 22) & 31)) & (word >> ((h >> 17) & 31)) & 1u;
+}
+
+// Third stage for one (window, pattern index) pair whose fingerprint matched.
+__device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p, uint32_t pi) {
+  const uint2 pp = a.pat40[pi];
+  const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
+  const uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ull;
+  if (__popcll(mm) > a.k) return;                     // packed distance never exceeds the true one
+  // exact distance on the raw stream codes
+  const int L = a.pat_len[pi];
+  const int64_t start = p + 1 - L;
+  if (start < 0) return;
+  const uint8_t *pc = a.pat_codes + (size_t)pi * 32;
+  int ham = 0;
+  uint32_t dirty = 0;                                 // pieces (of the last Lw bases) with a mismatch
+  bool left_clean = true, right_clean = true;
+  const int m = a.k + a.r;
+  for (int i = 0; i < L; ++i) {
+    const uint8_t tc = a.text[start + i];
+    if (a.cmap[tc] == 1) return;                      // EOS inside the window: never a candidate
+    if (tc != pc[i]) {
+      if (++ham > a.k) return;
+      if (i < L / 2) left_clean = false; else right_clean = false;
+      const int j = i - (L - a.Lw);                   // position inside the seeded suffix
+      if (j >= 0 && j / a.pb < m) dirty |= 1u << (j / a.pb);
     }
-    if (dead) continue;
-    // report once: only through the combo made of the first r clean pieces
-    uint64_t first = 0;
-    const uint64_t field = (1ull << (2 * a.pb)) - 1ull;
-    for (int j = 0, t = 0; j < m && t < a.r; ++j)
-      if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
-    if (first != (((uint64_t)mhi << 32) | mlo)) continue;
-    const unsigned long long o = atomicAdd(a.counter, 1ull);
-    if (o < a.cap) {
-      pm_hit hh;
-      hh.end = p + 1; hh.pid = a.pat_id[pi]; hh.k = (uint8_t)ham;
-      hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
-      a.out[o] = hh;
-    }
+  }
+  // report once: only through the combo made of the first r clean pieces
+  uint64_t first = 0;
+  const uint64_t field = (1ull << (2 * a.pb)) - 1ull;
+  for (int j = 0, t = 0; j < m && t < a.r; ++j)
+    if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
+  if (first != (((uint64_t)mhi << 32) | mlo)) return;
+  const unsigned long long o = atomicAdd(a.counter, 1ull);
+  if (o < a.cap) {
+    pm_hit hh;
+    hh.end = p + 1; hh.pid = a.pat_id[pi]; hh.k = (uint8_t)ham;
+    hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
+    a.out[o] = hh;
   }
 }
 
+// Second stage.  A 32-byte bucket (two 16-byte loads issued together) holds 8 fingerprinted
+// slots; the probe sequence ends at the first bucket with a free slot, which is almost always the
+// first one.  check_bucket tests the slots of a bucket that is already in registers.
+__device__ __forceinline__ bool check_bucket(const SeedArgs &a, const uint4 &q0, const uint4 &q1, uint32_t fp, uint32_t imask,
+                                             uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
+  const uint32_t sl[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (sl[i] == EMPTY) return true;
+    if ((sl[i] & ~imask) == fp) verify_pattern(a, mlo, mhi, W, p, sl[i] & imask);
+  }
+  return false;
+}
+
+// continue a probe sequence from bucket b (rare: only after a full bucket)
+__device__ __forceinline__ void probe_from(const SeedArgs &a, const uint4 *buckets, uint32_t b, uint32_t fp, uint32_t imask,
+                                           uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
+  const uint32_t bmask = (1u << (32 - a.bucket_shift)) - 1u;
+  for (;;) {
+    b &= bmask;
+    const uint4 q0 = buckets[2 * (size_t)b], q1 = buckets[2 * (size_t)b + 1];
+    if (check_bucket(a, q0, q1, fp, imask, mlo, mhi, W, p)) break;
+    ++b;
+  }
+}
+
+
 // LW > 0: window length known at compile time (all shifts immediate); LW == 0: taken from a.Lw.
-template <int LW>
+// MODE: see window_hash.
+template <int LW, int MODE>
 __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   uint32_t *bloom = lds;                                          // SEED_BLOOM_WORDS dwords
@@ -159,7 +197,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 
   // blockIdx -> (combo, chunk): runs of `group` chunks share a combo, all combos of a superchunk
   // follow each other, so the stream bytes of a superchunk are re-read from MALL and the combo's
-  // slot table stays in every XCD's L2 while a run is in flight.
+  // bucket table stays in every XCD's L2 while a run is in flight.
   const int per_super = a.group * a.ncombos;
   const int sc = blockIdx.x / per_super;
   const int rem = blockIdx.x - sc * per_super;
@@ -194,8 +232,8 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   if (own_lo < Lw - 1) own_lo = Lw - 1;                           // the window must fit in the stream
   if (own_lo >= own_hi) return;
 
-  const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo];
-  const uint2 *slots = a.slots + (size_t)combo * (a.slot_mask + 1);
+  const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo], sel = a.perm_sel[combo];
+  const uint4 *buckets = a.buckets + (size_t)combo * 2 * ((size_t)1 << (32 - a.bucket_shift));
   const int sh = a.ascii ? 1 : 0;
   // the 32 bases in front of the wave's range
   uint32_t carry1, carry2;
@@ -216,20 +254,51 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     if (s < 32) { wlo = __builtin_amdgcn_alignbit(prev1, prev2, s); whi = __builtin_amdgcn_alignbit(cur, prev1, s); }
     else if (s < 64) { wlo = __builtin_amdgcn_alignbit(cur, prev1, s - 32); whi = cur >> (s - 32); }
     else { wlo = cur >> (s - 64); whi = 0; }
-    wlo &= lo_mask; whi &= hi_mask;
+    if (MODE == 0 || LW == 0) { wlo &= lo_mask; whi &= hi_mask; }
   };
+  const uint32_t imask = (1u << a.idx_bits) - 1u;
+  // second stage on full waves of survivors: every lane takes up to three queued windows and has
+  // all their buckets in flight at once, so a drain is one memory round trip
   auto drain = [&]() {
-    for (int q = lane; q < qn; q += 64) {
-      const uint2 e = queue[q];
-      verify_entry(a, slots, mlo, mhi, e.x, e.y & 0xffu, ws + (e.y >> 8));
-    }
+    if (!(a.debug & 1))
+      for (int base = 0; base < qn; base += 192) {
+        uint32_t wl[3], wh[3], ps[3], h2[3];
+        uint4 b0[3], b1[3];
+        bool on[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int q = base + 64 * j + lane;
+          on[j] = q < qn;
+          if (on[j]) {
+            const uint2 e = queue[q];
+            wl[j] = e.x; wh[j] = e.y & 0xffu; ps[j] = e.y >> 8;
+            h2[j] = window_hash<MODE>(wl[j], wh[j], mlo, mhi, sel) * HASH_SLOT;
+            const size_t b = h2[j] >> a.bucket_shift;
+            b0[j] = buckets[2 * b]; b1[j] = buckets[2 * b + 1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (on[j]) {
+            const uint64_t W = ((uint64_t)(wh[j] & hi_mask) << 32) | (wl[j] & lo_mask);
+            if (!check_bucket(a, b0[j], b1[j], h2[j] << a.idx_bits, imask, mlo, mhi, W, ws + ps[j]))
+              probe_from(a, buckets, (h2[j] >> a.bucket_shift) + 1, h2[j] << a.idx_bits, imask, mlo, mhi, W, ws + ps[j]);
+          }
+      }
     qn = 0;
   };
 
-  uint4 vnext = load16(a.text, ws + 16 * lane, a.n);
+
+  // four 1-KiB blocks of the stream in flight per wave (64 KiB per CU): rolling prefetch ring
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  uint4 q0 = load16(a.text, ws + 16 * lane, a.n);
+  uint4 q1 = ws + 1024 < own_hi ? load16(a.text, ws + 1024 + 16 * lane, a.n) : zero4;
+  uint4 q2 = ws + 2048 < own_hi ? load16(a.text, ws + 2048 + 16 * lane, a.n) : zero4;
+  uint4 q3 = ws + 3072 < own_hi ? load16(a.text, ws + 3072 + 16 * lane, a.n) : zero4;
   for (int64_t bb = ws; bb < own_hi; bb += 1024) {
-    const uint4 v = vnext;
-    if (bb + 1024 < own_hi) vnext = load16(a.text, bb + 1024 + 16 * lane, a.n);   // next block in flight
+    const uint4 v = q0;
+    q0 = q1; q1 = q2; q2 = q3;
+    if (bb + 4096 < own_hi) q3 = load16(a.text, bb + 4096 + 16 * lane, a.n);
     const uint32_t cur = pack16(v, sh);
     uint32_t prev1 = __shfl_up(cur, 1), prev2 = __shfl_up(cur, 2);
     if (lane == 0) { prev1 = carry1; prev2 = carry2; }
@@ -245,53 +314,36 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
     }
     // first stage, part 1: 16 hashes, 16 LDS reads in flight
-    uint32_t wl[16], hs[16], wd[16];
+    uint32_t hs[16], wd[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      uint32_t whi;
-      window(i, prev2, prev1, cur, wl[i], whi);
-      hs[i] = window_hash(wl[i], whi, mlo, mhi);
-      wd[i] = bloom[hs[i] >> 17];
+      uint32_t wlo, whi;
+      window(i, prev2, prev1, cur, wlo, whi);
+      hs[i] = window_hash<MODE>(wlo, whi, mlo, mhi, sel);
+      wd[i] = bloom[hs[i] & (SEED_BLOOM_WORDS - 1)];
     }
-    // part 2: tests -> per-lane survivor bits and the wave total
-    uint32_t pbits = 0;
-    int total = 0;
+    // part 2: three bit tests per window; the verdicts are funnelled into one register
+    uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const uint32_t bm = bloom_bits(hs[i]);
-      const bool pass = ((wd[i] & bm) == bm) && (own >> i & 1u);
-      total += __popcll(__ballot(pass));
-      pbits |= pass ? (1u << i) : 0u;
-    }
-    if (qn + total > QCAP) drain();                               // second stage on full waves of survivors
-    if (total <= QCAP) {
-      // part 3: ballot + mbcnt compaction into the wave's queue
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const bool pass = pbits >> i & 1u;
-        const unsigned long long bal = __ballot(pass);
-        if (pass) {
-          uint32_t wlo, whi;
-          window(i, prev2, prev1, cur, wlo, whi);
-          const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-          queue[slot] = make_uint2(wlo, whi | ((uint32_t)(pbase + i - ws) << 8));
-        }
-        qn += __popcll(bal);
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_alignbit(bloom_test(wd[i], hs[i]), acc, 1);
+    uint32_t rem = (acc >> 16) & own;
+    // part 3: compaction, one survivor per lane and round (ballot + mbcnt give the queue slots)
+    for (;;) {
+      const unsigned long long bal = __ballot(rem != 0);
+      if (bal == 0) break;
+      if (qn + 64 > QCAP) drain();
+      if (rem != 0) {
+        const int i = __ffs(rem) - 1;
+        rem &= rem - 1;
+        const int sft = 2 * (i - Lw + 33);                         // per-lane bit offset of the window
+        const uint32_t x0 = __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = __builtin_amdgcn_alignbit(cur, prev1, sft),
+                       x2 = cur >> (sft & 31);
+        const uint32_t wlo = sft < 32 ? x0 : (sft < 64 ? x1 : x2);
+        const uint32_t whi = sft < 32 ? x1 : (sft < 64 ? x2 : 0u);
+        const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        queue[slot] = make_uint2(wlo, (whi & 0xffu) | ((uint32_t)(pbase + i - ws) << 8));
       }
-    } else {
-      // a block with more survivors than the queue holds (low-complexity stream): step by step
-      for (int i = 0; i < 16; ++i) {
-        if (qn + 64 > QCAP) drain();
-        const bool pass = pbits >> i & 1u;
-        const unsigned long long bal = __ballot(pass);
-        if (pass) {
-          uint32_t wlo, whi;
-          window(i, prev2, prev1, cur, wlo, whi);
-          const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-          queue[slot] = make_uint2(wlo, whi | ((uint32_t)(pbase + i - ws) << 8));
-        }
-        qn += __popcll(bal);
-      }
+      qn += __popcll(bal);
     }
   }
   drain();
@@ -333,18 +385,26 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.maxlen = lmax;
   t.Lw = std::min(lmin, 20);
   // choose m = k + r pieces of pb bases: fewest filter lookups + verifies
-  double best = 1e300;
-  const double P = std::max<size_t>(pats.size(), 1);
-  for (int r = 1; r <= 4; ++r) {
-    const int m = k + r, pb = std::min(t.Lw / m, 16 / r);
-    if (pb < 1 || m > 8) continue;
-    const double C = (double)binom(m, r);
-    if (C > SEED_MAX_COMBOS) continue;
-    double keys = 1; for (int i = 0; i < r * pb; ++i) keys *= 4;
-    const double cost = C * 1.1 + 20.0 * C * P / keys;
-    if (cost < best) { best = cost; t.r = r; t.pb = pb; }
+  t.mode = 0;
+  if (t.Lw == 20 && k <= 2) {
+    // 4-base pieces are bytes of the packed window: one v_perm builds the key
+    t.pb = 4;
+    t.r = k == 0 ? 4 : 3;
+    t.mode = k == 0 ? 2 : 1;
+  } else {
+    double best = 1e300;
+    const double P = std::max<size_t>(pats.size(), 1);
+    for (int r = 1; r <= 4; ++r) {
+      const int m = k + r, pb = std::min(t.Lw / m, 16 / r);
+      if (pb < 1 || m > 8) continue;
+      const double C = (double)binom(m, r);
+      if (C > SEED_MAX_COMBOS) continue;
+      double keys = 1; for (int i = 0; i < r * pb; ++i) keys *= 4;
+      const double cost = C * 1.1 + 20.0 * C * P / keys;
+      if (cost < best) { best = cost; t.r = r; t.pb = pb; }
+    }
+    if (best > 1e299) return "patterns too short for a k-mismatch seed plan";
   }
-  if (best > 1e299) return "patterns too short for a k-mismatch seed plan";
   const int m = k + t.r;
   // enumerate combos (r-subsets of m pieces) in lexicographic order
   std::vector<int> c(t.r);
@@ -360,13 +420,26 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
     for (int j = i + 1; j < t.r; ++j) c[j] = c[j - 1] + 1;
   }
   const int C = (int)t.combos.size();
+  t.perm_sel.assign(C, 0);
+  for (int ci = 0; ci < C; ++ci) {
+    uint32_t sel = 0;
+    for (int q = 0; q < 4; ++q) sel |= (q < t.r ? (uint32_t)t.combos[ci][q] : 0x0cu) << (8 * q);
+    t.perm_sel[ci] = sel;
+  }
   const size_t np = pats.size();
   t.pat40.resize(np); t.pat_len.resize(np); t.pat_id.resize(np); t.pat_codes.assign(np * 32, 0);
-  size_t nslots = 1024;
-  while (nslots < 2 * np) nslots <<= 1;
+  // buckets of 8 slots, average fill <= 3; slot = fingerprint (high bits) | pattern index (low idx_bits)
+  int idx_bits = 1;
+  while (((size_t)1 << idx_bits) <= np) ++idx_bits;
+  size_t nbuckets = 256;
+  while (nbuckets * 3 < np) nbuckets <<= 1;
+  int lb = 0;
+  while (((size_t)1 << lb) < nbuckets) ++lb;
+  t.idx_bits = idx_bits; t.bucket_shift = 32 - lb;
+  const size_t nslots = nbuckets * 8;
   t.nslots = nslots;
   t.bloom.assign((size_t)C * SEED_BLOOM_WORDS, 0);
-  t.slots.assign((size_t)C * nslots * 2, EMPTY);
+  t.slots.assign((size_t)C * nslots, EMPTY);
   for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
   if (eos_code >= 0 && eos_code < 256) t.cmap[eos_code] = 1;
   const uint64_t pmask = (1ull << (2 * t.pb)) - 1ull;
@@ -382,12 +455,22 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
     for (int ci = 0; ci < C; ++ci) {
       uint64_t cm = 0;
       for (int q = 0; q < t.r; ++q) cm |= pmask << (2 * t.pb * t.combos[ci][q]);
-      const uint32_t h = window_hash((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)cm, (uint32_t)(cm >> 32));
-      t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h >> 17)] |= (1u << ((h >> 12) & 31)) | (1u << ((h >> 7) & 31)) | (1u << ((h >> 2) & 31));
-      uint32_t idx = ((h * HASH_SLOT) >> 7) & (uint32_t)(nslots - 1);
-      uint32_t *sl = &t.slots[(size_t)ci * nslots * 2];
-      while (sl[2 * idx + 1] != EMPTY) idx = (idx + 1) & (uint32_t)(nslots - 1);
-      sl[2 * idx] = h; sl[2 * idx + 1] = (uint32_t)j;
+      const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32), mlo = (uint32_t)cm, mhi = (uint32_t)(cm >> 32);
+      const uint32_t h = t.mode == 0 ? window_hash<0>(wlo, whi, mlo, mhi, 0)
+                       : t.mode == 1 ? window_hash<1>(wlo, whi, mlo, mhi, t.perm_sel[ci])
+                                     : window_hash<2>(wlo, whi, mlo, mhi, t.perm_sel[ci]);
+      t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h & (SEED_BLOOM_WORDS - 1))] |=
+          (1u << ((h >> 27) & 31)) | (1u << ((h >> 22) & 31)) | (1u << ((h >> 17) & 31));
+      const uint32_t h2 = h * HASH_SLOT;
+      const uint32_t imask = (1u << idx_bits) - 1u;
+      uint32_t b = h2 >> t.bucket_shift;
+      uint32_t *tb = &t.slots[(size_t)ci * nslots];
+      for (;;) {                                   // first bucket with a free slot; probes stop at such a bucket
+        int q = 0;
+        while (q < 8 && tb[(size_t)b * 8 + q] != EMPTY) ++q;
+        if (q < 8) { tb[(size_t)b * 8 + q] = ((h2 << idx_bits) & ~imask) | (uint32_t)j; break; }
+        b = (b + 1) & (uint32_t)(nbuckets - 1);
+      }
     }
   }
   return "";
@@ -396,12 +479,14 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   seed_free(d);
   d->k = t.k; d->Lw = t.Lw; d->pb = t.pb; d->r = t.r; d->ascii = t.ascii; d->maxlen = t.maxlen;
-  d->ncombos = (int)t.combos.size(); d->nslots = t.nslots;
+  d->ncombos = (int)t.combos.size(); d->nslots = t.nslots; d->idx_bits = t.idx_bits; d->bucket_shift = t.bucket_shift;
   for (int c = 0; c < d->ncombos; ++c) {
     uint64_t cm = 0;
     for (int q = 0; q < t.r; ++q) cm |= ((1ull << (2 * t.pb)) - 1ull) << (2 * t.pb * t.combos[c][q]);
     d->mask_lo[c] = (uint32_t)cm; d->mask_hi[c] = (uint32_t)(cm >> 32);
+    d->perm_sel[c] = t.perm_sel[c];
   }
+  d->mode = t.mode;
   auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
     if (e != hipSuccess) return e;
@@ -415,10 +500,10 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
   if ((e = up(t.pat_codes.data(), t.pat_codes.size(), (void **)&d->pat_codes)) != hipSuccess) return e;
   if ((e = up(t.cmap, 256, (void **)&d->cmap)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_seed_scan<20>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SEED_LDS_BYTES)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_seed_scan<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SEED_LDS_BYTES)) != hipSuccess) return e;
+  const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1>), reinterpret_cast<const void *>(pm_seed_scan<20, 2>),
+                           reinterpret_cast<const void *>(pm_seed_scan<20, 0>), reinterpret_cast<const void *>(pm_seed_scan<0, 0>)};
+  for (const void *kf : kernels)
+    if ((e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, SEED_LDS_BYTES)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
 }
 
@@ -456,13 +541,19 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   a.group = 256;                                                   // one run ~ one chunk per CU
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
+  a.debug = 0;
+  if (const char *env = getenv("PM_SEED_DEBUG")) a.debug = atoi(env);
   memcpy(a.mask_lo, d.mask_lo, sizeof(a.mask_lo));
   memcpy(a.mask_hi, d.mask_hi, sizeof(a.mask_hi));
-  a.bloom = d.bloom; a.slots = reinterpret_cast<const uint2 *>(d.slots); a.slot_mask = (uint32_t)(d.nslots - 1);
+  memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
+  a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
-  if (d.Lw == 20) hipLaunchKernelGGL(pm_seed_scan<20>, dim3(g.blocks), dim3(SEED_THREADS), SEED_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(pm_seed_scan<0>, dim3(g.blocks), dim3(SEED_THREADS), SEED_LDS_BYTES, st, a);
+  const dim3 grid(g.blocks), block(SEED_THREADS);
+  if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1>), grid, block, SEED_LDS_BYTES, st, a);
+  else if (d.Lw == 20 && d.mode == 2) hipLaunchKernelGGL((pm_seed_scan<20, 2>), grid, block, SEED_LDS_BYTES, st, a);
+  else if (d.Lw == 20) hipLaunchKernelGGL((pm_seed_scan<20, 0>), grid, block, SEED_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((pm_seed_scan<0, 0>), grid, block, SEED_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

@@ -243,13 +243,14 @@ class PatternMatch:
         self._check(self._L.pm_candidates_device(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def finalize(self, cands, scanned_to, last=True):
+    def finalize(self, cands, scanned_to, last=True, sort=True):
         cands = np.ascontiguousarray(cands, dtype=HIT_DTYPE)
-        out = np.zeros(max(cands.size, 1), dtype=HIT_DTYPE)
+        out = np.empty(max(cands.size, 1), dtype=HIT_DTYPE)
         n_out = C.c_size_t()
-        self._check(self._L.pm_finalize(self._h, cands.ctypes.data_as(C.c_void_p), cands.size, scanned_to, int(last),
+        self._check(self._L.pm_finalize(self._h, cands.ctypes.data_as(C.c_void_p), cands.size, scanned_to,
+                                        (1 if last else 0) | (2 if sort else 0),
                                         out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
-        return out[:n_out.value].copy()
+        return out[:n_out.value]
 
     def selected(self):
         return self._L.pm_selected_semantics(self._h), self._L.pm_selected_kernel(self._h)
