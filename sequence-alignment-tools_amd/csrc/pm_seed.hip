@@ -83,8 +83,20 @@ __device__ __noinline__ uint4 load16_edge(const uint8_t *text, int64_t off, int6
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte stream load.  NT (single-combo plans: the stream is read exactly once) marks it
+// non-temporal so that it does not push the bucket table out of L2; multi-combo plans want the
+// superchunk to stay in MALL for the following combos and use the default policy.
+template <bool NT>
 __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_t n) {
-  if (off >= 0 && off + 16 <= n) return *reinterpret_cast<const uint4 *>(text + off);
+  if (off >= 0 && off + 16 <= n) {
+    if (NT) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(text + off));
+      return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4 *>(text + off);
+  }
   return load16_edge(text, off, n);
 }
 
@@ -213,8 +225,8 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   if (cj >= a.nchunks || combo >= a.ncombos) return;
 
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.bloom + (size_t)combo * SEED_BLOOM_WORDS);
-    uint4 *dst = reinterpret_cast<uint4 *>(bloom);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.bloom + (size_t)combo * SEED_BLOOM_WORDS);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(bloom);
     for (int i = threadIdx.x; i < SEED_BLOOM_WORDS / 4; i += SEED_THREADS) dst[i] = src[i];
   }
   __syncthreads();
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   // the 32 bases in front of the wave's range
   uint32_t carry1, carry2;
   {
-    const uint4 v = load16(a.text, ws - 32 + 16 * (lane & 1), a.n);
+    const uint4 v = load16<MODE == 2>(a.text, ws - 32 + 16 * (lane & 1), a.n);
     const uint32_t pk = pack16(v, sh);
     carry2 = __builtin_amdgcn_readlane(pk, 0);
     carry1 = __builtin_amdgcn_readlane(pk, 1);
@@ -291,14 +303,14 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 
   // four 1-KiB blocks of the stream in flight per wave (64 KiB per CU): rolling prefetch ring
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  uint4 q0 = load16(a.text, ws + 16 * lane, a.n);
-  uint4 q1 = ws + 1024 < own_hi ? load16(a.text, ws + 1024 + 16 * lane, a.n) : zero4;
-  uint4 q2 = ws + 2048 < own_hi ? load16(a.text, ws + 2048 + 16 * lane, a.n) : zero4;
-  uint4 q3 = ws + 3072 < own_hi ? load16(a.text, ws + 3072 + 16 * lane, a.n) : zero4;
+  uint4 q0 = load16<MODE == 2>(a.text, ws + 16 * lane, a.n);
+  uint4 q1 = ws + 1024 < own_hi ? load16<MODE == 2>(a.text, ws + 1024 + 16 * lane, a.n) : zero4;
+  uint4 q2 = ws + 2048 < own_hi ? load16<MODE == 2>(a.text, ws + 2048 + 16 * lane, a.n) : zero4;
+  uint4 q3 = ws + 3072 < own_hi ? load16<MODE == 2>(a.text, ws + 3072 + 16 * lane, a.n) : zero4;
   for (int64_t bb = ws; bb < own_hi; bb += 1024) {
     const uint4 v = q0;
     q0 = q1; q1 = q2; q2 = q3;
-    if (bb + 4096 < own_hi) q3 = load16(a.text, bb + 4096 + 16 * lane, a.n);
+    if (bb + 4096 < own_hi) q3 = load16<MODE == 2>(a.text, bb + 4096 + 16 * lane, a.n);
     const uint32_t cur = pack16(v, sh);
     uint32_t prev1 = __shfl_up(cur, 1), prev2 = __shfl_up(cur, 2);
     if (lane == 0) { prev1 = carry1; prev2 = carry2; }
