@@ -24,6 +24,8 @@ struct SeedTables {
   int idx_bits = 0, bucket_shift = 0;
   std::vector<uint32_t> bloom;                    // [combo][SEED_BLOOM_WORDS]
   std::vector<uint32_t> slots;                    // [combo][nbuckets][8]
+  std::vector<uint32_t> bitmap2;                  // [combo][2^(lb2-5)]
+  int lb2 = 0;
   struct P40 { uint32_t lo, hi; };
   std::vector<P40> pat40;
   std::vector<uint8_t> pat_len;
@@ -33,7 +35,8 @@ struct SeedTables {
 };
 
 struct SeedDevice {
-  uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr;
+  uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr, *bitmap2 = nullptr;
+  int lb2 = 0;
   void *pat40 = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr;
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};

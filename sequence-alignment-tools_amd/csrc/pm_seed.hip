@@ -53,6 +53,8 @@ struct SeedArgs {
   const uint32_t *bloom;                // [combo][SEED_BLOOM_WORDS]
   const uint4 *buckets;                 // [combo][nbuckets][2]: 8 slots of (fingerprint << idx_bits | pattern index)
   uint32_t bucket_shift, idx_bits;      // bucket = h2 >> bucket_shift; nbuckets = 2^(32-bucket_shift)
+  const uint32_t *bitmap2;              // [combo][2^(lb2-5)] second-level one-bit filter (L2 resident)
+  uint32_t lb2;                         // log2 of its size in bits
   const uint2 *pat40;                   // packed last Lw bases of every pattern
   const uint8_t *pat_len;
   const uint32_t *pat_id;
@@ -132,13 +134,9 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h) {
   return (word >> ((h >> 27) & 31)) & (word >> ((h >> 22) & 31)) & (word >> ((h >> 17) & 31)) & 1u;
 }
 
-// Third stage for one (window, pattern index) pair whose fingerprint matched.
-__device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p, uint32_t pi) {
-  const uint2 pp = a.pat40[pi];
-  const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
-  const uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ull;
-  if (__popcll(mm) > a.k) return;                     // packed distance never exceeds the true one
-  // exact distance on the raw stream codes
+// Third stage, exact part: (window ending at p, pattern pi) already passed the packed-distance
+// test; count mismatches on the raw stream codes (N = mismatch, EOS = reject) and report.
+__device__ __forceinline__ void verify_exact(const SeedArgs &a, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
   const int L = a.pat_len[pi];
   const int64_t start = p + 1 - L;
   if (start < 0) return;
@@ -170,6 +168,30 @@ __device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, 
     hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
     a.out[o] = hh;
   }
+}
+
+// packed distance (2 bits per base) never exceeds the true one: a cheap necessary condition
+__device__ __forceinline__ bool packed_close(const uint2 &pp, uint64_t W, int k) {
+  const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
+  return __popcll((x | (x >> 1)) & 0x5555555555555555ull) <= k;
+}
+
+__device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p, uint32_t pi) {
+  if (packed_close(a.pat40[pi], W, a.k)) verify_exact(a, mlo, mhi, p, pi);
+}
+
+// slots of a loaded bucket whose fingerprint matches, as a bit mask; bit 8 = the bucket is full
+// (the probe sequence continues in the next bucket)
+__device__ __forceinline__ uint32_t match_mask(const uint4 &q0, const uint4 &q1, uint32_t fp, uint32_t imask) {
+  const uint32_t sl[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  uint32_t mm = 0;
+  bool open = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    open = open || sl[i] == EMPTY;
+    if (!open && (sl[i] & ~imask) == fp) mm |= 1u << i;
+  }
+  return mm | (open ? 0u : 256u);
 }
 
 // Second stage.  A 32-byte bucket (two 16-byte loads issued together) holds 8 fingerprinted
@@ -246,6 +268,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 
   const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo], sel = a.perm_sel[combo];
   const uint4 *buckets = a.buckets + (size_t)combo * 2 * ((size_t)1 << (32 - a.bucket_shift));
+  const uint32_t *bitmap2 = a.bitmap2 + (size_t)combo * ((size_t)1 << (a.lb2 - 5));
   const int sh = a.ascii ? 1 : 0;
   // the 32 bases in front of the wave's range
   uint32_t carry1, carry2;
@@ -269,37 +292,83 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     if (MODE == 0 || LW == 0) { wlo &= lo_mask; whi &= hi_mask; }
   };
   const uint32_t imask = (1u << a.idx_bits) - 1u;
-  // second stage on full waves of survivors: every lane takes up to three queued windows and has
-  // all their buckets in flight at once, so a drain is one memory round trip
-  auto drain = [&]() {
-    if (!(a.debug & 1))
-      for (int base = 0; base < qn; base += 192) {
-        uint32_t wl[3], wh[3], ps[3], h2[3];
-        uint4 b0[3], b1[3];
-        bool on[3];
+  // Second stage on full waves of survivors, software pipelined: when the queue fills up, every
+  // lane takes up to three queued windows into registers and issues their loads from the small
+  // second-level bitmap (2a); the wave then goes back to the first stage and only looks at the
+  // answers when the queue is full again -- ~95 % of the Bloom false positives die there without
+  // the wave ever waiting for memory.  What is left gets its bucket loaded and checked (2b).
+  // (scalars, not arrays: the state must stay in VGPRs across the block loop)
+  uint32_t pw0 = 0, pw1 = 0, pw2 = 0, px0 = 0, px1 = 0, px2 = 0, ph0 = 0, ph1 = 0, ph2 = 0, pb0 = 0, pb1 = 0, pb2 = 0;
+  int pend = 0;                                                   // wave-uniform: windows in flight
+  auto finish = [&]() __attribute__((always_inline)) {
+    if (pend == 0) return;
+    const uint32_t pw[3] = {pw0, pw1, pw2}, px[3] = {px0, px1, px2}, ph[3] = {ph0, ph1, ph2}, pb[3] = {pb0, pb1, pb2};
+    uint4 b0[3], b1[3];
+    uint2 pp[3];
+    uint32_t mm[3], pidx[3] = {0, 0, 0};
+    bool on[3];
+    // 2b: all bucket loads of the batch in flight together
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int q = base + 64 * j + lane;
-          on[j] = q < qn;
-          if (on[j]) {
-            const uint2 e = queue[q];
-            wl[j] = e.x; wh[j] = e.y & 0xffu; ps[j] = e.y >> 8;
-            h2[j] = window_hash<MODE>(wl[j], wh[j], mlo, mhi, sel) * HASH_SLOT;
-            const size_t b = h2[j] >> a.bucket_shift;
-            b0[j] = buckets[2 * b]; b1[j] = buckets[2 * b + 1];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (on[j]) {
-            const uint64_t W = ((uint64_t)(wh[j] & hi_mask) << 32) | (wl[j] & lo_mask);
-            if (!check_bucket(a, b0[j], b1[j], h2[j] << a.idx_bits, imask, mlo, mhi, W, ws + ps[j]))
-              probe_from(a, buckets, (h2[j] >> a.bucket_shift) + 1, h2[j] << a.idx_bits, imask, mlo, mhi, W, ws + ps[j]);
-          }
+    for (int j = 0; j < 3; ++j) {
+      on[j] = (64 * j + lane < pend) && ((pb[j] >> ((ph[j] >> (32 - a.lb2)) & 31)) & 1u);
+      if (on[j]) {
+        const size_t b = ph[j] >> a.bucket_shift;
+        b0[j] = buckets[2 * b]; b1[j] = buckets[2 * b + 1];
       }
+    }
+    // 3a: fingerprint compare, then the packed patterns of the first matches, again together
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      mm[j] = on[j] ? match_mask(b0[j], b1[j], ph[j] << a.idx_bits, imask) : 0u;
+      if (mm[j] & 255u) {
+        const int sidx = __ffs(mm[j]) - 1;
+        const uint32_t slot = sidx < 4 ? (sidx == 0 ? b0[j].x : sidx == 1 ? b0[j].y : sidx == 2 ? b0[j].z : b0[j].w)
+                                       : (sidx == 4 ? b1[j].x : sidx == 5 ? b1[j].y : sidx == 6 ? b1[j].z : b1[j].w);
+        pidx[j] = slot & imask;
+        pp[j] = a.pat40[pidx[j]];
+      }
+    }
+    // 3b: packed distance; exact verify, further matches and full buckets are rare
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (!(mm[j] & 511u)) continue;
+      const uint64_t W = ((uint64_t)(px[j] & 0xffu & hi_mask) << 32) | (pw[j] & lo_mask);
+      const int64_t p = ws + (px[j] >> 8);
+      if (mm[j] & 255u) {
+        if (packed_close(pp[j], W, a.k)) verify_exact(a, mlo, mhi, p, pidx[j]);
+        uint32_t rest = (mm[j] & 255u) & ((mm[j] & 255u) - 1u);     // matches beyond the first
+        while (rest) {
+          const int sidx = __ffs(rest) - 1;
+          rest &= rest - 1;
+          const uint32_t sl[8] = {b0[j].x, b0[j].y, b0[j].z, b0[j].w, b1[j].x, b1[j].y, b1[j].z, b1[j].w};
+          uint32_t slot = 0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
+          verify_pattern(a, mlo, mhi, W, p, slot & imask);
+        }
+      }
+      if (mm[j] & 256u) probe_from(a, buckets, (ph[j] >> a.bucket_shift) + 1, ph[j] << a.idx_bits, imask, mlo, mhi, W, p);
+    }
+    pend = 0;
+  };
+  auto issue_one = [&](int j, uint32_t &pw, uint32_t &px, uint32_t &ph, uint32_t &pb) __attribute__((always_inline)) {
+    const int q = 64 * j + lane;
+    if (q < qn) {
+      const uint2 e = queue[q];
+      pw = e.x; px = e.y;
+      ph = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
+      pb = bitmap2[ph >> (37 - a.lb2)];
+    }
+  };
+  auto drain = [&]() __attribute__((always_inline)) {             // qn <= QCAP = 192 = 3 per lane
+    if (a.debug & 1) { qn = 0; return; }
+    finish();
+    issue_one(0, pw0, px0, ph0, pb0);
+    issue_one(1, pw1, px1, ph1, pb1);
+    issue_one(2, pw2, px2, ph2, pb2);
+    pend = qn;
     qn = 0;
   };
-
 
   // four 1-KiB blocks of the stream in flight per wave (64 KiB per CU): rolling prefetch ring
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -359,6 +428,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     }
   }
   drain();
+  finish();
 }
 
 }  // namespace
@@ -451,6 +521,10 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   const size_t nslots = nbuckets * 8;
   t.nslots = nslots;
   t.bloom.assign((size_t)C * SEED_BLOOM_WORDS, 0);
+  int lb2 = 16;
+  while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2;
+  t.lb2 = lb2;
+  t.bitmap2.assign((size_t)C << (lb2 - 5), 0);
   t.slots.assign((size_t)C * nslots, EMPTY);
   for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
   if (eos_code >= 0 && eos_code < 256) t.cmap[eos_code] = 1;
@@ -474,6 +548,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h & (SEED_BLOOM_WORDS - 1))] |=
           (1u << ((h >> 27) & 31)) | (1u << ((h >> 22) & 31)) | (1u << ((h >> 17) & 31));
       const uint32_t h2 = h * HASH_SLOT;
+      t.bitmap2[((size_t)ci << (lb2 - 5)) + (h2 >> (37 - lb2))] |= 1u << ((h2 >> (32 - lb2)) & 31);
       const uint32_t imask = (1u << idx_bits) - 1u;
       uint32_t b = h2 >> t.bucket_shift;
       uint32_t *tb = &t.slots[(size_t)ci * nslots];
@@ -507,6 +582,8 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   hipError_t e;
   if ((e = up(t.bloom.data(), t.bloom.size() * 4, (void **)&d->bloom)) != hipSuccess) return e;
   if ((e = up(t.slots.data(), t.slots.size() * 4, (void **)&d->slots)) != hipSuccess) return e;
+  if ((e = up(t.bitmap2.data(), t.bitmap2.size() * 4, (void **)&d->bitmap2)) != hipSuccess) return e;
+  d->lb2 = t.lb2;
   if ((e = up(t.pat40.data(), t.pat40.size() * 8, (void **)&d->pat40)) != hipSuccess) return e;
   if ((e = up(t.pat_len.data(), t.pat_len.size(), (void **)&d->pat_len)) != hipSuccess) return e;
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
@@ -520,7 +597,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
 }
 
 void seed_free(SeedDevice *d) {
-  void *ptrs[] = {d->bloom, d->slots, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  void *ptrs[] = {d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = SeedDevice();
 }
@@ -559,6 +636,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   memcpy(a.mask_hi, d.mask_hi, sizeof(a.mask_hi));
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
   a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
+  a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   const dim3 grid(g.blocks), block(SEED_THREADS);
