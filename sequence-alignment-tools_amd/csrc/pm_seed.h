@@ -10,10 +10,11 @@
 namespace pm {
 
 constexpr int SEED_THREADS = 1024;                // 16 waves per workgroup, one workgroup per CU (LDS bound)
-constexpr int SEED_QCAP = 192;                    // survivor queue entries per wave
+constexpr int SEED_QCAP = 128;                    // first survivor queue (Bloom survivors), entries per wave
+constexpr int SEED_Q2CAP = 112;                   // second queue (second-level bitmap survivors)
 constexpr int SEED_BLOOM_WORDS = 32768;           // 128 KiB blocked Bloom filter per combo
 constexpr int SEED_MAX_COMBOS = 16;
-constexpr int SEED_LDS_BYTES = SEED_BLOOM_WORDS * 4 + (SEED_THREADS / 64) * SEED_QCAP * 8;   // filter + wave queues
+constexpr int SEED_LDS_BYTES = SEED_BLOOM_WORDS * 4 + (SEED_THREADS / 64) * (SEED_QCAP + SEED_Q2CAP) * 8;   // filter + wave queues
 
 struct SeedTables {
   int k = 0, Lw = 0, pb = 0, r = 0, maxlen = 0, mode = 0;

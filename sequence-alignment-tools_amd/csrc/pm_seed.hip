@@ -292,80 +292,91 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     if (MODE == 0 || LW == 0) { wlo &= lo_mask; whi &= hi_mask; }
   };
   const uint32_t imask = (1u << a.idx_bits) - 1u;
-  // Second stage on full waves of survivors, software pipelined: when the queue fills up, every
-  // lane takes up to three queued windows into registers and issues their loads from the small
-  // second-level bitmap (2a); the wave then goes back to the first stage and only looks at the
-  // answers when the queue is full again -- ~95 % of the Bloom false positives die there without
-  // the wave ever waiting for memory.  What is left gets its bucket loaded and checked (2b).
+  // Second stage, two queues per wave.
+  //   Q1 <- Bloom survivors (~11 % of the tests).  When it fills up, every lane takes up to two
+  //   of its windows into registers and issues their loads from the small second-level bitmap
+  //   (stage 2a); the wave goes back to the first stage and only looks at the answers when Q1 is
+  //   full again, so this round trip is never waited for.
+  //   Q2 <- the ~5 % of Q1 that the bitmap lets through.  Only when 64 of them have gathered does
+  //   the wave load their buckets and packed patterns (stages 2b/3): one dense pass instead of a
+  //   mostly idle one per Q1 batch.
+  uint2 *queue2 = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_WORDS) + WAVES * QCAP + wave * SEED_Q2CAP;
+  int q2n = 0;
+  auto process_q2 = [&]() __attribute__((always_inline)) {
+    for (int base = 0; base < q2n; base += 64) {
+      const bool on = base + lane < q2n;
+      uint32_t wlo = 0, whi = 0, h2 = 0, mm = 0, pidx = 0;
+      int64_t p = 0;
+      uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+      uint2 pp = make_uint2(0, 0);
+      if (on) {
+        const uint2 e = queue2[base + lane];
+        wlo = e.x & lo_mask; whi = e.y & 0xffu & hi_mask; p = ws + (e.y >> 8);
+        h2 = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
+        const size_t b = h2 >> a.bucket_shift;
+        b0 = buckets[2 * b]; b1 = buckets[2 * b + 1];
+        mm = match_mask(b0, b1, h2 << a.idx_bits, imask);
+      }
+      const uint32_t sl[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      if (mm & 255u) {
+        const int sidx = __ffs(mm) - 1;
+        uint32_t slot = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
+        pidx = slot & imask;
+        pp = a.pat40[pidx];
+      }
+      if (mm & 511u) {
+        const uint64_t W = ((uint64_t)whi << 32) | wlo;
+        if (mm & 255u) {
+          if (packed_close(pp, W, a.k)) verify_exact(a, mlo, mhi, p, pidx);
+          uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);         // matches beyond the first (rare)
+          while (rest) {
+            const int sidx = __ffs(rest) - 1;
+            rest &= rest - 1;
+            uint32_t slot = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
+            verify_pattern(a, mlo, mhi, W, p, slot & imask);
+          }
+        }
+        if (mm & 256u) probe_from(a, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
+      }
+    }
+    q2n = 0;
+  };
   // (scalars, not arrays: the state must stay in VGPRs across the block loop)
-  uint32_t pw0 = 0, pw1 = 0, pw2 = 0, px0 = 0, px1 = 0, px2 = 0, ph0 = 0, ph1 = 0, ph2 = 0, pb0 = 0, pb1 = 0, pb2 = 0;
+  uint32_t pw0 = 0, pw1 = 0, px0 = 0, px1 = 0, pb0 = 0, pb1 = 0, pt0 = 0, pt1 = 0;
   int pend = 0;                                                   // wave-uniform: windows in flight
+  auto finish_one = [&](int j, uint32_t pw, uint32_t px, uint32_t pb, uint32_t pt) __attribute__((always_inline)) {
+    const bool pass = (64 * j + lane < pend) && ((pb >> (pt & 31)) & 1u);
+    const unsigned long long bal = __ballot(pass);
+    if (bal == 0) return;
+    if (q2n + 64 > SEED_Q2CAP) process_q2();
+    if (pass) queue2[q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))] = make_uint2(pw, px);
+    q2n += __popcll(bal);
+  };
   auto finish = [&]() __attribute__((always_inline)) {
     if (pend == 0) return;
-    const uint32_t pw[3] = {pw0, pw1, pw2}, px[3] = {px0, px1, px2}, ph[3] = {ph0, ph1, ph2}, pb[3] = {pb0, pb1, pb2};
-    uint4 b0[3], b1[3];
-    uint2 pp[3];
-    uint32_t mm[3], pidx[3] = {0, 0, 0};
-    bool on[3];
-    // 2b: all bucket loads of the batch in flight together
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      on[j] = (64 * j + lane < pend) && ((pb[j] >> ((ph[j] >> (32 - a.lb2)) & 31)) & 1u);
-      if (on[j]) {
-        const size_t b = ph[j] >> a.bucket_shift;
-        b0[j] = buckets[2 * b]; b1[j] = buckets[2 * b + 1];
-      }
-    }
-    // 3a: fingerprint compare, then the packed patterns of the first matches, again together
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      mm[j] = on[j] ? match_mask(b0[j], b1[j], ph[j] << a.idx_bits, imask) : 0u;
-      if (mm[j] & 255u) {
-        const int sidx = __ffs(mm[j]) - 1;
-        const uint32_t slot = sidx < 4 ? (sidx == 0 ? b0[j].x : sidx == 1 ? b0[j].y : sidx == 2 ? b0[j].z : b0[j].w)
-                                       : (sidx == 4 ? b1[j].x : sidx == 5 ? b1[j].y : sidx == 6 ? b1[j].z : b1[j].w);
-        pidx[j] = slot & imask;
-        pp[j] = a.pat40[pidx[j]];
-      }
-    }
-    // 3b: packed distance; exact verify, further matches and full buckets are rare
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (!(mm[j] & 511u)) continue;
-      const uint64_t W = ((uint64_t)(px[j] & 0xffu & hi_mask) << 32) | (pw[j] & lo_mask);
-      const int64_t p = ws + (px[j] >> 8);
-      if (mm[j] & 255u) {
-        if (packed_close(pp[j], W, a.k)) verify_exact(a, mlo, mhi, p, pidx[j]);
-        uint32_t rest = (mm[j] & 255u) & ((mm[j] & 255u) - 1u);     // matches beyond the first
-        while (rest) {
-          const int sidx = __ffs(rest) - 1;
-          rest &= rest - 1;
-          const uint32_t sl[8] = {b0[j].x, b0[j].y, b0[j].z, b0[j].w, b1[j].x, b1[j].y, b1[j].z, b1[j].w};
-          uint32_t slot = 0;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
-          verify_pattern(a, mlo, mhi, W, p, slot & imask);
-        }
-      }
-      if (mm[j] & 256u) probe_from(a, buckets, (ph[j] >> a.bucket_shift) + 1, ph[j] << a.idx_bits, imask, mlo, mhi, W, p);
-    }
+    finish_one(0, pw0, px0, pb0, pt0);
+    if (pend > 64) finish_one(1, pw1, px1, pb1, pt1);
     pend = 0;
   };
-  auto issue_one = [&](int j, uint32_t &pw, uint32_t &px, uint32_t &ph, uint32_t &pb) __attribute__((always_inline)) {
+  auto issue_one = [&](int j, uint32_t &pw, uint32_t &px, uint32_t &pb, uint32_t &pt) __attribute__((always_inline)) {
     const int q = 64 * j + lane;
     if (q < qn) {
       const uint2 e = queue[q];
       pw = e.x; px = e.y;
-      ph = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
-      pb = bitmap2[ph >> (37 - a.lb2)];
+      const uint32_t h2 = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
+      pt = h2 >> (32 - a.lb2);                                     // bit index inside the bitmap
+      pb = bitmap2[h2 >> (37 - a.lb2)];
     }
   };
-  auto drain = [&]() __attribute__((always_inline)) {             // qn <= QCAP = 192 = 3 per lane
+  auto drain = [&]() __attribute__((always_inline)) {             // qn <= QCAP = 128 = 2 per lane
     if (a.debug & 1) { qn = 0; return; }
     finish();
-    issue_one(0, pw0, px0, ph0, pb0);
-    issue_one(1, pw1, px1, ph1, pb1);
-    issue_one(2, pw2, px2, ph2, pb2);
+    issue_one(0, pw0, px0, pb0, pt0);
+    issue_one(1, pw1, px1, pb1, pt1);
     pend = qn;
     qn = 0;
   };
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   }
   drain();
   finish();
+  process_q2();
 }
 
 }  // namespace
