@@ -193,6 +193,26 @@ def main():
     final_hits = [0]
     cand_count = [0]
 
+    out_buf = np.empty(1 << 24, dtype=sat_amd.HIT_DTYPE)          # host landing zone for final hits
+    dev_final = [True]                                              # GPU clustering available for this option set?
+
+    def finalize_rank0(ptr, cnt, scanned_to):
+        """records in HBM -> final hits on the host of rank 0"""
+        if dev_final[0]:
+            try:
+                return pm.finalize_device(scanned_to, last=True, sort=False, d_cands=ptr, n=cnt, out=out_buf)
+            except sat_amd.PmError as e:
+                if e.code != -2:
+                    raise
+                dev_final[0] = False
+        if world > 1 and pm.selected()[0] == sat_amd.SEM_EXACT_HALVES and args.indels:
+            raise SystemExit("bench.py --gpus>1: -k with exact_halves needs stream text in the verify stage (DESIGN.md 5)")
+        cands = np.zeros(cnt, dtype=sat_amd.HIT_DTYPE)
+        if cnt:
+            cands = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).cpu().numpy().view(sat_amd.HIT_DTYPE)
+        pm.reset()
+        return pm.finalize(cands, scanned_to, last=True, sort=False)
+
     def step():
         pm.scan_async(begin, end)
         ncand = pm.scan_wait()
@@ -200,49 +220,33 @@ def main():
         kernel_ms.append(ms)
         ptr, cnt = pm.candidates_device()
         if world == 1:
-            cands = np.zeros(cnt, dtype=sat_amd.HIT_DTYPE)
-            if cnt:
-                t = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev)
-                cands = t.cpu().numpy().view(sat_amd.HIT_DTYPE)
-        else:
-            # the path's one real exchange: variable-length hit records to rank 0 over xGMI
-            counts = torch.zeros(world, dtype=torch.int64, device=dev)
-            mine = torch.tensor([cnt], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(counts, mine)
-            mx = int(counts.max().item())
-            pad = torch.zeros(max(mx, 1) * 16, dtype=torch.uint8, device=dev)
-            if cnt:
-                pad[:cnt * 16] = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev)
-            gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, gathered, dst=0)
-            cands = None
-            if rank == 0:
-                parts = []
-                cl = counts.cpu().tolist()
-                for r in range(world):
-                    a = gathered[r][:cl[r] * 16].cpu().numpy().view(sat_amd.HIT_DTYPE).copy()
-                    a["end"] += max(0, r * shard - HALO)                    # local -> global stream index
-                    parts.append(a)
-                cands = np.concatenate(parts) if parts else np.zeros(0, dtype=sat_amd.HIT_DTYPE)
+            cand_count[0] = cnt
+            final_hits[0] = finalize_rank0(ptr, cnt, end).size
+            return ncand
+        # the path's one real exchange: variable-length hit records to rank 0 over xGMI
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([cnt], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, mine)
+        cl = counts.cpu().tolist()
+        mx = max(max(cl), 1)
+        pad = torch.zeros(mx * 2, dtype=torch.int64, device=dev)    # a record = two int64 words
+        if cnt:
+            pad[:cnt * 2] = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).view(torch.int64)
+        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, gathered, dst=0)
         if rank == 0:
-            cand_count[0] = cands.size
-            if world == 1:
-                pm.reset()
-                hits = pm.finalize(cands, end, last=True, sort=False)
-            else:
-                hits = finalize_global(cands)
-            final_hits[0] = hits.size
+            parts = []
+            for r in range(world):
+                a = gathered[r][:cl[r] * 2].view(-1, 2)
+                a[:, 0] += max(0, r * shard - HALO)                  # local -> global stream index
+                parts.append(a)
+            allrec = torch.cat(parts).contiguous()
+            torch.cuda.current_stream().synchronize()
+            tot = allrec.shape[0]
+            cand_count[0] = tot
+            scanned = int(total)
+            final_hits[0] = finalize_rank0(allrec.data_ptr(), tot, scanned).size
         return ncand
-
-    def finalize_global(cands):
-        # rank 0 only sees its own shard's text; the default -K search needs no text to cluster
-        # (levels decide), see DESIGN.md "multi-GPU finalize"
-        if pm.selected()[0] not in (sat_amd.SEM_KEYWORD_TREE, sat_amd.SEM_SHIFT_AND, sat_amd.SEM_SHIFT_AND_INEXACT) and \
-                not (pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC and not args.indels):
-            raise SystemExit("bench.py --gpus>1: this option set needs stream text in the verify stage; "
-                             "supported multi-GPU runs are k=0 and -K k (see DESIGN.md)")
-        pm.reset()
-        return pm.finalize(cands, int(cands["end"].max()) + 1 if cands.size else 0, last=True, sort=False)
 
     for _ in range(args.warmup):
         step()

@@ -135,6 +135,14 @@ int pm_set_capacity(pm_handle *h, size_t max_candidates);
 int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, int flags,
                 pm_hit *out, size_t cap, size_t *n_out);
 
+/* Device form of pm_finalize: the records are in HBM (d_cands, or NULL = those of the last
+ * pm_scan_candidates), the sort + clustering runs on the GPU and only final hits cross PCIe into
+ * `out`.  Available where the host stage needs neither stream text nor sequential state: exact
+ * engines, bare shift_and_inexact, and filter_bitvec with -K and no exact-base constraints
+ * (PM_E_UNSUPPORTED otherwise: use pm_finalize). */
+int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
+                       pm_hit *out, size_t cap, size_t *n_out);
+
 /* PatternMatch::reset (pattern_match.h:134): forget scan state, keep patterns and text. */
 int pm_reset(pm_handle *h);
 void pm_destroy(pm_handle *h);

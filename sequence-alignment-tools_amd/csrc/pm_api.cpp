@@ -78,6 +78,15 @@ struct pm_handle {
   int64_t *d_wstart = nullptr; int32_t *d_wlen = nullptr; int64_t *d_woff = nullptr; uint8_t *d_wout = nullptr;
   size_t d_wcap = 0, d_woutcap = 0;
 
+  // device finalize workspace (pm_finalize_device)
+  uint64_t *d_keys = nullptr, *d_keys_alt = nullptr;
+  void *d_ctemp = nullptr;
+  size_t ckeys_cap = 0, ctemp_bytes = 0;
+  pm_hit *d_fout = nullptr, *d_fleft = nullptr;
+  unsigned long long *d_fcounts = nullptr, *h_fcounts = nullptr;
+  uint8_t *d_fpat_len = nullptr;
+  uint32_t *d_fpat_id = nullptr;
+
   std::string err;
 };
 
@@ -153,6 +162,11 @@ static void free_device(pm_handle *h) {
   if (h->d_wlen) (void)hipFree(h->d_wlen);
   if (h->d_woff) (void)hipFree(h->d_woff);
   if (h->d_wout) (void)hipFree(h->d_wout);
+  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id};
+  for (void *q : fw) if (q) (void)hipFree(q);
+  if (h->h_fcounts) (void)hipHostFree(h->h_fcounts);
+  h->d_keys = h->d_keys_alt = nullptr; h->d_ctemp = nullptr; h->d_fout = h->d_fleft = nullptr; h->d_fcounts = nullptr;
+  h->h_fcounts = nullptr; h->d_fpat_len = nullptr; h->d_fpat_id = nullptr; h->ckeys_cap = 0; h->ctemp_bytes = 0;
   h->d_cands = nullptr; h->d_counter = nullptr; h->h_counter = nullptr; h->d_text = nullptr;
   h->ev0 = h->ev1 = nullptr; h->d_wstart = nullptr; h->d_wlen = nullptr; h->d_woff = nullptr; h->d_wout = nullptr;
   h->d_wcap = h->d_woutcap = 0;
@@ -486,6 +500,11 @@ int fetch_windows(pm_handle *h, std::vector<Window> &wins) {
     }
     if (h->d_woutcap < (size_t)total) {
       if (h->d_wout) (void)hipFree(h->d_wout);
+  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id};
+  for (void *q : fw) if (q) (void)hipFree(q);
+  if (h->h_fcounts) (void)hipHostFree(h->h_fcounts);
+  h->d_keys = h->d_keys_alt = nullptr; h->d_ctemp = nullptr; h->d_fout = h->d_fleft = nullptr; h->d_fcounts = nullptr;
+  h->h_fcounts = nullptr; h->d_fpat_len = nullptr; h->d_fpat_id = nullptr; h->ckeys_cap = 0; h->ctemp_bytes = 0;
       h->d_woutcap = (size_t)total * 2;
       HIP_TRY(h, hipMalloc((void **)&h->d_wout, h->d_woutcap));
     }
@@ -713,6 +732,83 @@ extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
   if (n_out) *n_out = outv.size();
   if (outv.size() > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize: out buffer too small");
   if (!outv.empty()) memcpy(out, outv.data(), outv.size() * sizeof(pm_hit));
+  return PM_OK;
+}
+
+// Device form of pm_finalize for the option sets whose host stage needs no stream text and no
+// order-dependent state: exact engines and bare shift_and_inexact (pass-through) and
+// filter_bitvec with -K and no exact-base constraints (sort + segmented pass, pm_cluster.hip).
+// d_cands == NULL means "the records of the last pm_scan_candidates".  Final hits are copied to
+// `out` (host).  The few clusters the device cannot decide (still growing at scanned_to, or
+// starting inside the first L characters) go through the host stage.
+extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
+                                  pm_hit *out, size_t cap, size_t *n_out) {
+  if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_finalize_device: handle not initialised");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const pm_hit *src = d_cands ? (const pm_hit *)d_cands : h->d_cands;
+  if (!d_cands) n = h->last_count;
+  const bool last = flags & PM_FINALIZE_LAST;
+  if (n_out) *n_out = 0;
+  const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT;
+  bool cluster = h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.indels && h->cfg.k <= 3 && h->pats.size() < ((size_t)1 << 22);
+  if (cluster) for (const Pattern &p : h->pats) if (p.esb || p.eeb) { cluster = false; break; }
+  if (!passthrough && !cluster) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this option set needs the host stage (pm_finalize)");
+  if (passthrough) {
+    if (n > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
+    if (n) HIP_TRY(h, hipMemcpyAsync(out, src, n * sizeof(pm_hit), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (flags & PM_FINALIZE_SORTED) std::sort(out, out + n, by_end_pid);
+    if (n_out) *n_out = n;
+    return PM_OK;
+  }
+  // workspace
+  if (h->ckeys_cap < n || !h->d_keys) {
+    void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft};
+    for (void *q : fw) if (q) (void)hipFree(q);
+    h->ckeys_cap = std::max<size_t>(n + n / 4, (size_t)1 << 16);
+    HIP_TRY(h, hipMalloc((void **)&h->d_keys, h->ckeys_cap * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_keys_alt, h->ckeys_cap * 8));
+    h->ctemp_bytes = cluster_temp_bytes(h->ckeys_cap);
+    HIP_TRY(h, hipMalloc(&h->d_ctemp, h->ctemp_bytes ? h->ctemp_bytes : 16));
+    HIP_TRY(h, hipMalloc((void **)&h->d_fout, h->ckeys_cap * sizeof(pm_hit)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_fleft, h->ckeys_cap * sizeof(pm_hit)));
+  }
+  if (!h->d_fcounts) {
+    HIP_TRY(h, hipMalloc((void **)&h->d_fcounts, 2 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipHostMalloc((void **)&h->h_fcounts, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
+    for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
+    HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));
+    HIP_TRY(h, hipMalloc((void **)&h->d_fpat_id, pi.size() ? pi.size() * 4 : 4));
+    if (!pl.empty()) {
+      HIP_TRY(h, hipMemcpy(h->d_fpat_len, pl.data(), pl.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  // carried candidates from an earlier call join the batch on the host side (they are few)
+  std::vector<pm_hit> hostpart;
+  hostpart.swap(h->carry);
+  HIP_TRY(h, cluster_device(src, n, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, h->d_keys, h->d_keys_alt,
+                            h->d_ctemp, h->ctemp_bytes, h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const size_t nfin = (size_t)h->h_fcounts[0], nleft = (size_t)h->h_fcounts[1];
+  if (nleft) {
+    const size_t at = hostpart.size();
+    hostpart.resize(at + nleft);
+    HIP_TRY(h, hipMemcpy(hostpart.data() + at, h->d_fleft, nleft * sizeof(pm_hit), hipMemcpyDeviceToHost));
+  }
+  std::vector<pm_hit> extra;
+  if (!hostpart.empty()) {
+    int rc = finalize_into(h, hostpart.data(), hostpart.size(), scanned_to, last, extra);
+    if (rc) return rc;
+  }
+  if (nfin + extra.size() > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
+  if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));
+  if (!extra.empty()) memcpy(out + nfin, extra.data(), extra.size() * sizeof(pm_hit));
+  const size_t tot = nfin + extra.size();
+  if (flags & PM_FINALIZE_SORTED) std::sort(out, out + tot, by_end_pid);
+  if (n_out) *n_out = tot;
   return PM_OK;
 }
 

@@ -72,4 +72,12 @@ const char *bitpar_kernel_name(int k, bool indels);
 hipError_t gather_windows(const uint8_t *d_text, int64_t n, const int64_t *d_starts, const int32_t *d_lens,
                           const int64_t *d_offsets, int count, uint8_t *d_out, hipStream_t st);
 
+
+// ---- device clustering for -K filter_bitvec (pm_cluster.hip) ----------------------------------
+size_t cluster_temp_bytes(size_t n);
+hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_to, bool last,
+                          const uint8_t *d_pat_len, const uint32_t *d_pat_id,
+                          uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                          pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
+
 }  // namespace pm

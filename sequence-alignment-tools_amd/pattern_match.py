@@ -20,6 +20,7 @@ PM_E_OVERFLOW = -5
 ABI_SYMBOLS = [
     "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_candidates",
     "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
+    "pm_finalize_device",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics",
 ]
@@ -76,6 +77,7 @@ def load_library():
         L.pm_candidates_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.pm_set_capacity.argtypes = [C.c_void_p, C.c_size_t]
         L.pm_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.pm_finalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_reset.argtypes = [C.c_void_p]
         L.pm_selected_semantics.argtypes = [C.c_void_p]
         L.pm_selected_kernel.argtypes = [C.c_void_p]
@@ -250,6 +252,18 @@ class PatternMatch:
         self._check(self._L.pm_finalize(self._h, cands.ctypes.data_as(C.c_void_p), cands.size, scanned_to,
                                         (1 if last else 0) | (2 if sort else 0),
                                         out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+        return out[:n_out.value]
+
+    def finalize_device(self, scanned_to, last=True, sort=True, d_cands=None, n=0, out=None):
+        """GPU clustering of the records of the last scan (or of `d_cands`, a device pointer);
+        returns the final hits (host array).  Raises PmError(-2) where only the host stage applies."""
+        if out is None:
+            cap = max(n if d_cands else self.candidates_device()[1], 1) + 1024
+            out = np.empty(cap, dtype=HIT_DTYPE)
+        n_out = C.c_size_t()
+        self._check(self._L.pm_finalize_device(self._h, C.c_void_p(d_cands or 0), n, scanned_to,
+                                               (1 if last else 0) | (2 if sort else 0),
+                                               out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
         return out[:n_out.value]
 
     def selected(self):

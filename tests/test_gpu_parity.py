@@ -153,3 +153,37 @@ def test_candidate_overflow_is_reported_and_recovered():
     hits = pm.find_all()
     assert hits.size == 5000 - 8 + 1
     pm.close()
+
+
+def test_device_finalize_equals_host_finalize():
+    """pm_finalize_device (hipCUB sort + segmented pass on the GPU) == the host stage, incl. clusters
+    on tandem repeats and the deferral at the end of a partial range."""
+    c, codes, table, allp = load([p for p in CASES if "varlen_repeats" in p][0])
+    n = codes.size
+    for k in (1, 2):
+        pm = sat_amd.PatternMatch(k=k, indels=False, semantics=sat_amd.SEM_FILTER_BITVEC)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        cands = pm.scan_candidates(0, n)
+        host = sat_amd.sorted_tuples(pm.finalize(cands, n, last=True))
+        pm.reset()
+        pm.scan_candidates(0, n, to_host=False)
+        dev = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
+        assert dev == host and len(host) > 0, (k, len(dev), len(host))
+        # two ranges: the first finalize must hold back clusters that may still grow
+        pm.reset()
+        cut = n // 2
+        pm.scan_candidates(0, cut, to_host=False)
+        a = sat_amd.sorted_tuples(pm.finalize_device(cut, last=False))
+        pm.scan_candidates(cut, n, to_host=False)
+        b = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
+        assert sorted(a + b) == host, (k, "split")
+        pm.close()
+    pm = sat_amd.PatternMatch(k=1, indels=True)
+    pm.add_pattern("ACGTACGTACGTACGTACGT", 1)
+    pm.init(codes, table)
+    pm.scan_candidates(0, n, to_host=False)
+    with pytest.raises(sat_amd.PmError):
+        pm.finalize_device(n)
+    pm.close()
