@@ -150,12 +150,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("PM_BENCH_BACKEND", "nccl")   # "gloo": rehearse N>1 on a 1-GPU box (collectives via host)
+    local = local % ndev if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if backend == "nccl" else torch.device("cpu")       # where collective buffers live
     log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
 
     # ---- synthetic inputs (untimed) ----------------------------------------------------------
@@ -171,7 +178,7 @@ def main():
         primers = None
     if world > 1:
         box = [primers]
-        dist.broadcast_object_list(box, src=0)
+        dist.broadcast_object_list(box, src=0, device=cdev)
         primers = box[0]
     allp = primers + [sat_amd.reverse_comp(p) for p in primers]
     kern = {"auto": sat_amd.KERNEL_AUTO, "bitpar": sat_amd.KERNEL_BITPAR, "seed": sat_amd.KERNEL_SEED}[args.kernel]
@@ -224,20 +231,20 @@ def main():
             final_hits[0] = finalize_rank0(ptr, cnt, end).size
             return ncand
         # the path's one real exchange: variable-length hit records to rank 0 over xGMI
-        counts = torch.zeros(world, dtype=torch.int64, device=dev)
-        mine = torch.tensor([cnt], dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(counts, mine)
-        cl = counts.cpu().tolist()
+        mine = torch.tensor([cnt], dtype=torch.int64, device=cdev)
+        clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(clist, mine)
+        cl = [int(x.item()) for x in clist]
         mx = max(max(cl), 1)
-        pad = torch.zeros(mx * 2, dtype=torch.int64, device=dev)    # a record = two int64 words
+        pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)   # a record = two int64 words
         if cnt:
-            pad[:cnt * 2] = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).view(torch.int64)
+            pad[:cnt * 2] = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).view(torch.int64).to(cdev)
         gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, gathered, dst=0)
         if rank == 0:
             parts = []
             for r in range(world):
-                a = gathered[r][:cl[r] * 2].view(-1, 2)
+                a = gathered[r][:cl[r] * 2].view(-1, 2).to(dev)
                 a[:, 0] += max(0, r * shard - HALO)                  # local -> global stream index
                 parts.append(a)
             allrec = torch.cat(parts).contiguous()
@@ -257,7 +264,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
