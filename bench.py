@@ -94,7 +94,7 @@ def cpu_baseline(args, stream0, primers_fwd, log):
     k, indels = args.k, bool(args.indels)
     sample = args.cpu_sample
     if sample <= 0:
-        sample = {0: 4_000_000, 1: 2_000_000}.get(k, 48_000)
+        sample = {0: 40_000_000, 1: 20_000_000}.get(k, 100_000)     # ~10-30 s of single-thread CPU work
     sample = min(sample, stream0.numel())
     codes = stream0[:sample].cpu().numpy()
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
@@ -126,6 +126,20 @@ def cpu_baseline(args, stream0, primers_fwd, log):
     return {"value": sample / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": kind,
             "sample": "first %d bases of the rank-0 shard, all %d primers x 2 strands, wall %.1f s incl. index build"
                       % (sample, len(primers_fwd), dt)}
+
+
+def measured_traffic(args, shard):
+    """HBM/fabric bytes per launch of the scan kernel from the committed PMC passes
+    (profiles/traffic_r*.json, produced by scripts/profile_round.sh), or None when this exact
+    workload was not profiled."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+        with open(f) as fh:
+            for e in json.load(fh).get("entries", []):
+                if (e["k"], e["indels"], e["db_bases"], e["primers"]) == (args.k, args.indels, shard, args.primers):
+                    best = e["traffic_bytes"]
+    return best
 
 
 def main():
@@ -287,7 +301,7 @@ def main():
                        "semantics": pm.selected()[0], "kernel_family": pm.selected()[1], "kernel": desc,
                        "final_hits": final_hits[0], "candidates": cand_count[0]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, shard),
                          "kernel_ms": kms, "algorithmic_bytes": alg_bytes},
         }
         if not args.no_cpu and args.cpu_sample >= 0 and world == 1:
