@@ -143,6 +143,14 @@ int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to,
 int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                        pm_hit *out, size_t cap, size_t *n_out);
 
+/* The caller's per-hit re-alignment (primer_match.cc:1135-1151, pcr_match.cc:1108-1127):
+ * exact_alignment::align (pattern_alignment.cc:29-43) for k == 0, otherwise
+ * editdist_alignment(key,key,k,eos,wc,tn,indels,dm,esb,eeb,false)::align with traceback
+ * (pattern_alignment.cc:117-705).  start/end are stream indices (pa->start(), pa->end());
+ * editdist is pa->editdist(), INT32_MAX for a constraint violation ("Bogus hit"). */
+typedef struct { int64_t start, end; int32_t editdist, value; } pm_alignment;
+int pm_align_hits(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out);
+
 /* PatternMatch::reset (pattern_match.h:134): forget scan state, keep patterns and text. */
 int pm_reset(pm_handle *h);
 void pm_destroy(pm_handle *h);

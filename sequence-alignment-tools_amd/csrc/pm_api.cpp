@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <unordered_map>
 
 #include "pm_internal.h"
 #include "pm_seed.h"
@@ -35,6 +36,7 @@ void Alphabet::set_table(const uint8_t *table, int len) {      // char_io.t:222-
 struct pm_handle {
   pm_config cfg{};
   std::vector<Pattern> pats;
+  std::unordered_map<uint32_t, uint32_t> id2idx;   // caller's pattern id -> index into pats
   Alphabet alpha;
   int eos_code = -1;
   int sem = 0, kern = 0;
@@ -145,6 +147,7 @@ extern "C" int pm_add_pattern(pm_handle *h, const char *pat, size_t len, uint64_
   if (h->inited) return fail(h, PM_E_INVALID, "pm_add_pattern after pm_init");
   if (id == 0) id = h->pats.size() + 1;                            // pattern_match.h:92-94
   if (id > 0xffffffffull) return fail(h, PM_E_UNSUPPORTED, "pattern ids above 2^32-1");
+  h->id2idx[(uint32_t)id] = (uint32_t)h->pats.size();
   h->pats.push_back(Pattern{std::string(pat, len), id, esb, eeb});
   return PM_OK;
 }
@@ -809,6 +812,37 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
   const size_t tot = nfin + extra.size();
   if (flags & PM_FINALIZE_SORTED) std::sort(out, out + tot, by_end_pid);
   if (n_out) *n_out = tot;
+  return PM_OK;
+}
+
+// primer_match's per-hit re-alignment (reference primer_match.cc:1135-1151): exact_alignment
+// (pattern_alignment.cc:29-43) for k == 0, else editdist_alignment(key, key, k, eos, wc, tn,
+// indels, dm, esb, eeb, yesno=false) with its traceback; editdist == INT32_MAX is the CLI's
+// "Bogus hit" (constraint violation).
+extern "C" int pm_align_hits(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out) {
+  if (!h || !h->inited || (!hits && n) || (!out && n)) return fail(h, PM_E_INVALID, "pm_align_hits: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const int k = h->cfg.k;
+  std::vector<Window> wins(n);
+  std::vector<const Pattern *> pp(n);
+  for (size_t i = 0; i < n; ++i) {
+    auto it = h->id2idx.find(hits[i].pid);
+    if (it == h->id2idx.end()) return fail(h, PM_E_INVALID, "pm_align_hits: unknown pattern id");
+    pp[i] = &h->pats[it->second];
+    const int L = (int)pp[i]->s.size();
+    int64_t ws = 0;
+    if (hits[i].end > (int64_t)L + k) ws = hits[i].end - L - k;       // pattern_alignment.cc:137-139
+    wins[i] = Window{ws, k == 0 ? 0 : (int32_t)(hits[i].end - ws), 0};
+  }
+  if (k > 0) { int rc = fetch_windows(h, wins); if (rc) return rc; }
+  AlignParams prm; prm.k = k; prm.indels = h->cfg.indels != 0; prm.eos = (uint8_t)h->cfg.eos;
+  for (size_t i = 0; i < n; ++i) {
+    const int L = (int)pp[i]->s.size();
+    if (k == 0) { out[i].start = hits[i].end - L; out[i].end = hits[i].end; out[i].editdist = 0; out[i].value = 0; continue; }
+    AlignResult r = editdist_align(h->winbuf.data() + wins[i].off, wins[i].start, hits[i].end, hits[i].end,
+                                   pp[i]->s.data(), L, pp[i]->esb, pp[i]->eeb, prm, h->scratch);
+    out[i].start = r.start; out[i].end = r.end; out[i].editdist = r.editdist; out[i].value = r.value;
+  }
   return PM_OK;
 }
 

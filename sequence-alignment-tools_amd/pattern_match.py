@@ -20,7 +20,7 @@ PM_E_OVERFLOW = -5
 ABI_SYMBOLS = [
     "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_candidates",
     "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
-    "pm_finalize_device",
+    "pm_finalize_device", "pm_align_hits",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics",
 ]
@@ -78,6 +78,7 @@ def load_library():
         L.pm_set_capacity.argtypes = [C.c_void_p, C.c_size_t]
         L.pm_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_finalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.pm_align_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.pm_reset.argtypes = [C.c_void_p]
         L.pm_selected_semantics.argtypes = [C.c_void_p]
         L.pm_selected_kernel.argtypes = [C.c_void_p]
@@ -265,6 +266,14 @@ class PatternMatch:
                                                (1 if last else 0) | (2 if sort else 0),
                                                out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
         return out[:n_out.value]
+
+    def align_hits(self, hits):
+        """primer_match's per-hit re-alignment; returns a structured array (start, end, editdist, value)."""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        out = np.zeros(hits.size, dtype=np.dtype([("start", "<i8"), ("end", "<i8"), ("editdist", "<i4"), ("value", "<i4")]))
+        if hits.size:
+            self._check(self._L.pm_align_hits(self._h, hits.ctypes.data_as(C.c_void_p), hits.size, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def selected(self):
         return self._L.pm_selected_semantics(self._h), self._L.pm_selected_kernel(self._h)

@@ -187,3 +187,55 @@ def test_device_finalize_equals_host_finalize():
     with pytest.raises(sat_amd.PmError):
         pm.finalize_device(n)
     pm.close()
+
+
+def test_cli_lines_via_align_hits():
+    """Engine hits + pm_align_hits (the CLI's per-hit re-alignment) reproduce the lines the real
+    primer_match prints with -A '%i %r %s %e %S %E %d' (tests/golden cli sections)."""
+    for path in CASES:
+        c, codes, table, allp = load(path)
+        n = len(c["patterns"])
+        starts, pos = [], 1
+        for s_ in c["entries"]:
+            starts.append(pos)
+            pos += len(s_) + 1
+        starts = np.array(starts)
+        for name, e in c["cli"].items():
+            pm = sat_amd.PatternMatch(k=e["k"], indels=e["indels"])
+            for i, p in enumerate(allp):
+                pm.add_pattern(p, i + 1)
+            pm.init(codes, table)
+            hits = pm.find_all()
+            al = pm.align_hits(hits)
+            lines = []
+            for h, a in zip(hits, al):
+                assert a["editdist"] <= e["k"], "bogus hit"
+                base = starts[np.searchsorted(starts, a["start"], side="right") - 1]
+                pid = int(h["pid"])
+                lines.append("%d %s %d %d %d %d %d" % (pid - n if pid > n else pid, "R" if pid > n else "F",
+                                                     a["start"] - base, a["end"] - base, a["start"], a["end"], a["editdist"]))
+            assert sorted(lines) == e["lines"], (c["name"], name)
+            pm.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_exact_base_constraints_vs_oracle(seed):
+    """-s/-e style exact_start_bases / exact_end_bases: exact_bases engine and the constrained
+    verifies of filter_bitvec / exact_halves (bit-parallel family + host DP)."""
+    rng = np.random.default_rng(900 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(400, 2000)), n_runs=2, repeats=(seed % 2 == 0))
+    L = int(rng.integers(16, 24))
+    pats = synth.make_patterns(rng, ents, int(rng.integers(10, 60)), length=L, planted=0.8, indel_frac=0.5)
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    text = O.Text(codes, table)
+    for esb, eeb in [(8, 0), (0, 7), (6, 9), (3, 0)]:
+        E, F = [esb] * len(allp), [eeb] * len(allp)
+        for sem, k, ind in [(sat_amd.SEM_AUTO, 1, True), (sat_amd.SEM_AUTO, 2, True), (sat_amd.SEM_AUTO, 2, False),
+                            (sat_amd.SEM_FILTER_BITVEC, 2, True), (sat_amd.SEM_EXACT_HALVES, 1, True)]:
+            eng = {sat_amd.SEM_AUTO: O.pick_engine(text, allp, k, ind, E, F), sat_amd.SEM_FILTER_BITVEC: 5,
+                   sat_amd.SEM_EXACT_HALVES: 12}[sem]
+            want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=ind, esb=E, eeb=F))
+            got = gpu_hits(codes, table, allp, sem, k, ind, sat_amd.KERNEL_AUTO, esb=E, eeb=F)
+            assert got == want, (seed, esb, eeb, sem, k, ind, eng, len(want), len(got))

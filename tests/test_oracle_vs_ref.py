@@ -31,3 +31,32 @@ def test_fuzz_against_reference(ref_harness, seed):
             eng = O.pick_engine(text, allp, k, bool(ind)) if sel == 0 else sel
             got = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=bool(ind)))
             assert got == ref, (seed, norm, sel, k, ind)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_fuzz_constraints_against_reference(ref_harness, seed):
+    """exact_start_bases / exact_end_bases (-s/-e): exact_bases and the constrained verifies."""
+    import os, subprocess, tempfile
+    rng = np.random.default_rng(500 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(200, 1200)), n_runs=2, repeats=(seed % 2 == 0))
+    L = int(rng.integers(16, 24))
+    pats = synth.make_patterns(rng, ents, int(rng.integers(5, 30)), length=L, planted=0.8, indel_frac=0.5)
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    text = O.Text(codes, table)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "db.sqn"), "wb").write(codes.tobytes())
+        open(os.path.join(d, "db.tbl"), "wb").write(table)
+        open(os.path.join(d, "pat.txt"), "w").write("\n".join(pats) + "\n")
+        for esb, eeb in [(8, 0), (0, 7), (6, 9), (3, 0)]:
+            for sel, k, ind in [(0, 1, 1), (0, 2, 1), (0, 2, 0), (8, 1, 1), (10, 2, 0), (5, 2, 1), (12, 1, 1)]:
+                cmd = [ref_harness, "-N", str(sel), "-n", "-r", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt"),
+                       "-s", str(esb), "-e", str(eeb), "-k" if ind else "-K", str(k)]
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                assert out.returncode == 0, out.stderr[-300:]
+                ref = sorted(tuple(int(x) for x in l.split()) for l in out.stdout.splitlines() if not l.startswith("#"))
+                E, F = [esb] * len(allp), [eeb] * len(allp)
+                eng = sel if sel else O.pick_engine(text, allp, k, bool(ind), E, F)
+                got = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=bool(ind), esb=E, eeb=F))
+                assert got == ref, (seed, esb, eeb, sel, k, ind)
