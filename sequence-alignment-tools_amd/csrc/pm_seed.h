@@ -38,7 +38,7 @@ struct SeedTables {
 struct SeedDevice {
   uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr, *bitmap2 = nullptr;
   int lb2 = 0;
-  void *pat40 = nullptr;
+  void *pat40 = nullptr, *d_args = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr;
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
   int mode = 0;

@@ -40,6 +40,7 @@ constexpr int WAVES = SEED_THREADS / 64;
 constexpr uint32_t EMPTY = 0xffffffffu;
 constexpr uint32_t HASH_LO = 0x9E3779B1u, HASH_HI = 0x9E3779u, HASH_SLOT = 0x85EBCA6Bu;
 
+struct SeedArgs;
 struct SeedArgs {
   const uint8_t *text;
   int64_t n, begin, end;                // owned hit ends: begin < end_pos <= end
@@ -63,6 +64,7 @@ struct SeedArgs {
   pm_hit *out;
   unsigned long long *counter;
   unsigned long long cap;
+  const SeedArgs *self;                 // device copy of this struct, for the out-of-line rare paths
 };
 
 __device__ __forceinline__ uint32_t pack4(uint32_t x, int sh) {
@@ -136,7 +138,8 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h) {
 
 // Third stage, exact part: (window ending at p, pattern pi) already passed the packed-distance
 // test; count mismatches on the raw stream codes (N = mismatch, EOS = reject) and report.
-__device__ __forceinline__ void verify_exact(const SeedArgs &a, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
+__device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
+  const SeedArgs &a = *ap;
   const int L = a.pat_len[pi];
   const int64_t start = p + 1 - L;
   if (start < 0) return;
@@ -177,7 +180,7 @@ __device__ __forceinline__ bool packed_close(const uint2 &pp, uint64_t W, int k)
 }
 
 __device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p, uint32_t pi) {
-  if (packed_close(a.pat40[pi], W, a.k)) verify_exact(a, mlo, mhi, p, pi);
+  if (packed_close(a.pat40[pi], W, a.k)) verify_exact(a.self, mlo, mhi, p, pi);
 }
 
 // slots of a loaded bucket whose fingerprint matches, as a bit mask; bit 8 = the bucket is full
@@ -209,8 +212,9 @@ __device__ __forceinline__ bool check_bucket(const SeedArgs &a, const uint4 &q0,
 }
 
 // continue a probe sequence from bucket b (rare: only after a full bucket)
-__device__ __forceinline__ void probe_from(const SeedArgs &a, const uint4 *buckets, uint32_t b, uint32_t fp, uint32_t imask,
-                                           uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
+__device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets, uint32_t b, uint32_t fp, uint32_t imask,
+                                        uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
+  const SeedArgs &a = *ap;
   const uint32_t bmask = (1u << (32 - a.bucket_shift)) - 1u;
   for (;;) {
     b &= bmask;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       if (mm & 511u) {
         const uint64_t W = ((uint64_t)whi << 32) | wlo;
         if (mm & 255u) {
-          if (packed_close(pp, W, a.k)) verify_exact(a, mlo, mhi, p, pidx);
+          if (packed_close(pp, W, a.k)) verify_exact(a.self, mlo, mhi, p, pidx);
           uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);         // matches beyond the first (rare)
           while (rest) {
             const int sidx = __ffs(rest) - 1;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
             verify_pattern(a, mlo, mhi, W, p, slot & imask);
           }
         }
-        if (mm & 256u) probe_from(a, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
+        if (mm & 256u) probe_from(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
       }
     }
     q2n = 0;
@@ -601,6 +605,8 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
   if ((e = up(t.pat_codes.data(), t.pat_codes.size(), (void **)&d->pat_codes)) != hipSuccess) return e;
   if ((e = up(t.cmap, 256, (void **)&d->cmap)) != hipSuccess) return e;
+  if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
+  static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1>), reinterpret_cast<const void *>(pm_seed_scan<20, 2>),
                            reinterpret_cast<const void *>(pm_seed_scan<20, 0>), reinterpret_cast<const void *>(pm_seed_scan<0, 0>)};
   for (const void *kf : kernels)
@@ -609,7 +615,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
 }
 
 void seed_free(SeedDevice *d) {
-  void *ptrs[] = {d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  void *ptrs[] = {d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = SeedDevice();
 }
@@ -651,6 +657,11 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
+  // the rare out-of-line paths read their parameters from a device copy of the argument block
+  if (!d.d_args) return hipErrorInvalidValue;
+  a.self = reinterpret_cast<const SeedArgs *>(d.d_args);
+  hipError_t ce = hipMemcpyAsync(d.d_args, &a, sizeof(a), hipMemcpyHostToDevice, st);
+  if (ce != hipSuccess) return ce;
   const dim3 grid(g.blocks), block(SEED_THREADS);
   if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20 && d.mode == 2) hipLaunchKernelGGL((pm_seed_scan<20, 2>), grid, block, SEED_LDS_BYTES, st, a);
