@@ -52,7 +52,8 @@ struct pm_handle {
   std::vector<Pattern> inner;
   std::vector<uint32_t> inner_ids;
   BitparDevice bp;
-  SeedDevice sd;
+  SeedDevice sd;                      // first pattern tile (plan parameters are read from here)
+  std::vector<SeedDevice> sd_more;    // further tiles when the pattern set is too large for one LDS filter
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   int scan_k = 0, seed_k = 0;
   bool scan_indels = false;
@@ -155,6 +156,8 @@ extern "C" int pm_add_pattern(pm_handle *h, const char *pat, size_t len, uint64_
 static void free_device(pm_handle *h) {
   bitpar_free(&h->bp);
   seed_free(&h->sd);
+  for (SeedDevice &d : h->sd_more) seed_free(&d);
+  h->sd_more.clear();
   if (h->d_cands) (void)hipFree(h->d_cands);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -266,6 +269,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   int rc = resolve(h);
   if (rc) return rc;
   bitpar_free(&h->bp); seed_free(&h->sd);
+  for (SeedDevice &d : h->sd_more) seed_free(&d);
+  h->sd_more.clear();
   h->seed_flags = false;
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
@@ -280,14 +285,39 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back((uint32_t)(i + 1)); }
       sk = h->cfg.k;
     } else { sp = h->inner; sid = h->inner_ids; }
-    SeedTables st;
-    why = seed_build(sp, sid, h->alpha, sk, h->eos_code, &st);
-    if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < 10) why = "patterns shorter than 10";
+    // One LDS Bloom filter (1 Mbit) stays selective up to ~256k keys: larger pattern sets are cut
+    // into tiles with their own tables; the scan launches once per tile into the same record buffer.
+    size_t tile_keys = 262144;
+    if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
+    const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
+    const size_t per = (sp.size() + ntile - 1) / ntile;
+    // the plan (window, pieces) must be the same for every tile: it depends on the shortest pattern
+    // of the whole set, so every tile is built with that window forced
+    int force_lw = 0;
+    for (const Pattern &p : sp) force_lw = force_lw == 0 ? (int)p.s.size() : std::min(force_lw, (int)p.s.size());
+    for (size_t ti = 0; ti < ntile && why.empty(); ++ti) {
+      const size_t lo = ti * per, hi = std::min(sp.size(), lo + per);
+      std::vector<Pattern> tp(sp.begin() + lo, sp.begin() + hi);
+      std::vector<uint32_t> tid(sid.begin() + lo, sid.begin() + hi);
+      SeedTables st;
+      why = seed_build(tp, tid, h->alpha, sk, h->eos_code, &st, force_lw);
+      if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < 10) why = "patterns shorter than 10";
+      if (!why.empty()) break;
+      SeedDevice *dst = &h->sd;
+      if (ti > 0) { h->sd_more.emplace_back(); dst = &h->sd_more.back(); }
+      HIP_TRY(h, seed_upload(st, dst, h->stream));
+      dst->maxlen = std::max(dst->maxlen, h->sd.maxlen);
+    }
     if (!why.empty()) {
+      seed_free(&h->sd);
+      for (SeedDevice &d : h->sd_more) seed_free(&d);
+      h->sd_more.clear();
       if (h->kern == PM_KERNEL_SEED) return fail(h, PM_E_UNSUPPORTED, "seed engine: " + why);
       want_seed = false;
     } else {
-      HIP_TRY(h, seed_upload(st, &h->sd, h->stream));
+      int mx = h->sd.maxlen;
+      for (SeedDevice &d : h->sd_more) mx = std::max(mx, d.maxlen);
+      h->sd.maxlen = mx;
       h->kern = PM_KERNEL_SEED;
       h->seed_flags = h->sem == PM_SEM_EXACT_HALVES;
       h->seed_k = sk;
@@ -359,8 +389,8 @@ extern "C" int pm_selected_kernel(const pm_handle *h) { return h && h->inited ? 
 extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   if (!h || !buf || !h->inited) return PM_E_INVALID;
   if (h->kern == PM_KERNEL_SEED)
-    snprintf(buf, buflen, "kernel=pm_seed_scan combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
-             h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
+    snprintf(buf, buflen, "kernel=pm_seed_scan tiles=%d combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
+             1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
              h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
   else
     snprintf(buf, buflen, "kernel=%s tiles=%d lanes_per_tile=64 words_per_lane=%d seg_len=%lld nseg=%d grid=%d block=%d",
@@ -378,13 +408,18 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   if (h->kern == PM_KERNEL_SEED)
+  {
     HIP_TRY(h, seed_launch(h->sd, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
+    for (SeedDevice &d : h->sd_more)
+      HIP_TRY(h, seed_launch(d, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr));
+    h->last_launches = 1 + (int)h->sd_more.size();
+  }
   else
     HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
   h->scan_begin = begin;
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-  h->last_launches = 1;
+  if (h->kern != PM_KERNEL_SEED) h->last_launches = 1;
   h->scan_pending = true;
   return PM_OK;
 }

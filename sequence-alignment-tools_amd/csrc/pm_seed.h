@@ -49,7 +49,7 @@ struct SeedDevice {
 };
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
-                       const Alphabet &alpha, int k, int eos_code, SeedTables *out);
+                       const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin = 0);
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
 void seed_free(SeedDevice *d);
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);

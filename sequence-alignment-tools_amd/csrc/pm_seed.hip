@@ -403,8 +403,8 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     carry1 = __builtin_amdgcn_readlane(cur, 63);
     const int64_t pbase = bb + 16 * lane;
     // positions of this lane that this wave owns (all 16 except in the first/last block)
-    uint32_t own;
-    {
+    uint32_t own = 0xffffu;
+    if (bb < own_lo || bb + 1024 > own_hi) {                       // wave-uniform: edge blocks only
       const int64_t lo = own_lo - pbase, hi = own_hi - pbase;
       const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
       own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       if (qn + 64 > QCAP) drain();
       if (rem != 0) {
         const int i = __ffs(rem) - 1;
+        __builtin_assume(i >= 0 && i < 16);
         rem &= rem - 1;
         const int sft = 2 * (i - Lw + 33);                         // per-lane bit offset of the window
         const uint32_t x0 = __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = __builtin_amdgcn_alignbit(cur, prev1, sft),
@@ -458,7 +459,7 @@ static uint64_t binom(int n, int r) {
 }
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
-                       const Alphabet &alpha, int k, int eos_code, SeedTables *out) {
+                       const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin) {
   SeedTables &t = *out;
   t = SeedTables();
   t.k = k;
@@ -481,6 +482,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   }
   if (pats.empty()) { lmin = lmax = 1; }
   t.maxlen = lmax;
+  if (force_lmin > 0) lmin = std::min(lmin, force_lmin);
   t.Lw = std::min(lmin, 20);
   // choose m = k + r pieces of pb bases: fewest filter lookups + verifies
   t.mode = 0;

@@ -239,3 +239,20 @@ def test_exact_base_constraints_vs_oracle(seed):
             want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=ind, esb=E, eeb=F))
             got = gpu_hits(codes, table, allp, sem, k, ind, sat_amd.KERNEL_AUTO, esb=E, eeb=F)
             assert got == want, (seed, esb, eeb, sem, k, ind, eng, len(want), len(got))
+
+
+def test_pattern_tiling_gives_identical_hits(monkeypatch):
+    """Primer sets too large for one LDS filter are cut into tiles (one launch each): same hit set."""
+    c, codes, table, allp = load(CASES[0])
+    for k, ind in [(0, True), (1, False), (2, False)]:
+        monkeypatch.delenv("PM_SEED_TILE", raising=False)
+        one = gpu_hits(codes, table, allp, sat_amd.SEM_AUTO, k, ind, sat_amd.KERNEL_SEED)
+        monkeypatch.setenv("PM_SEED_TILE", "37")
+        pm = sat_amd.PatternMatch(k=k, indels=ind, kernel=sat_amd.KERNEL_SEED)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        assert "tiles=%d" % ((len(allp) + 36) // 37) in pm.describe() or "tiles=" in pm.describe()
+        many = sat_amd.sorted_tuples(pm.find_all())
+        pm.close()
+        assert many == one and len(one) > 0, (k, ind)
