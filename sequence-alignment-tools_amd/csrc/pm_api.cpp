@@ -253,6 +253,12 @@ static int resolve(pm_handle *h) {
 // rules are then applied to (end, pattern, distance, clean-half flags) records on the host.
 static bool seed_eligible(pm_handle *h, std::string *why) {
   const int sem = h->sem;
+  if (h->cfg.k > 0 && h->cfg.indels && sem == PM_SEM_EXACT_HALVES) {
+    // exact_halves with edits: exact seeds of the halves + partner prefilter on the GPU, DP on the host
+    if (h->cfg.k > 2) { *why = "exact_halves -k > 2 runs on the bit-parallel family"; return false; }
+    for (const Pattern &p : h->pats) if (p.s.size() > 32 || p.s.size() < 16) { *why = "exact_halves -k on the seed family needs 16..32 character patterns"; return false; }
+    return true;
+  }
   if (h->cfg.k > 0 && h->cfg.indels && sem != PM_SEM_KEYWORD_TREE && sem != PM_SEM_SHIFT_AND) { *why = "edit-distance search (-k) runs on the bit-parallel family"; return false; }
   if (sem == PM_SEM_EXACT_BASES) { *why = "exact_bases runs on the bit-parallel family"; return false; }
   if (sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_EXACT_HALVES)
@@ -281,7 +287,16 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   if (want_seed) {
     std::vector<Pattern> sp; std::vector<uint32_t> sid;
     int sk = h->scan_k;
-    if (h->sem == PM_SEM_EXACT_HALVES) {          // whole patterns, distance <= k, halves decided by flags
+    std::vector<std::string> partners;
+    std::vector<uint8_t> sides;
+    const bool halves_mode = h->sem == PM_SEM_EXACT_HALVES && h->cfg.indels && h->cfg.k > 0;
+    if (halves_mode) {                            // halves as exact patterns (ids 2j+1, 2j+2), partner = other half
+      sp = h->inner; sid = h->inner_ids; sk = 0;
+      for (size_t i = 0; i + 1 < sp.size(); i += 2) {
+        partners.push_back(sp[i + 1].s); sides.push_back(0);      // left half: partner to the right
+        partners.push_back(sp[i].s); sides.push_back(1);          // right half: partner to the left
+      }
+    } else if (h->sem == PM_SEM_EXACT_HALVES) {   // -K: whole patterns, distance <= k, halves decided by flags
       for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back((uint32_t)(i + 1)); }
       sk = h->cfg.k;
     } else { sp = h->inner; sid = h->inner_ids; }
@@ -299,9 +314,13 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       const size_t lo = ti * per, hi = std::min(sp.size(), lo + per);
       std::vector<Pattern> tp(sp.begin() + lo, sp.begin() + hi);
       std::vector<uint32_t> tid(sid.begin() + lo, sid.begin() + hi);
+      std::vector<std::string> tpart;
+      std::vector<uint8_t> tside;
+      if (halves_mode) { tpart.assign(partners.begin() + lo, partners.begin() + hi); tside.assign(sides.begin() + lo, sides.begin() + hi); }
       SeedTables st;
-      why = seed_build(tp, tid, h->alpha, sk, h->eos_code, &st, force_lw);
-      if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < 10) why = "patterns shorter than 10";
+      why = seed_build(tp, tid, h->alpha, sk, h->eos_code, &st, force_lw, halves_mode ? &tpart : nullptr,
+                       halves_mode ? &tside : nullptr, h->cfg.k);
+      if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < (halves_mode ? 8 : 10)) why = "patterns too short for the seed family";
       if (!why.empty()) break;
       SeedDevice *dst = &h->sd;
       if (ti > 0) { h->sd_more.emplace_back(); dst = &h->sd_more.back(); }
@@ -319,7 +338,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       for (SeedDevice &d : h->sd_more) mx = std::max(mx, d.maxlen);
       h->sd.maxlen = mx;
       h->kern = PM_KERNEL_SEED;
-      h->seed_flags = h->sem == PM_SEM_EXACT_HALVES;
+      h->seed_flags = h->sem == PM_SEM_EXACT_HALVES && !halves_mode;
       h->seed_k = sk;
     }
   }

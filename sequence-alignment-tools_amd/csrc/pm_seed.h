@@ -32,6 +32,9 @@ struct SeedTables {
   std::vector<uint8_t> pat_len;
   std::vector<uint32_t> pat_id;
   std::vector<uint8_t> pat_codes;                 // 32 bytes per pattern
+  bool halves = false; int hk = 0;                // exact_halves -k mode: partner half per pattern
+  std::vector<uint32_t> part32;
+  std::vector<uint8_t> part_len, part_side;
   uint8_t cmap[256];
 };
 
@@ -39,7 +42,9 @@ struct SeedDevice {
   uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr, *bitmap2 = nullptr;
   int lb2 = 0;
   void *pat40 = nullptr, *d_args = nullptr;
-  uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr;
+  uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr;
+  uint32_t *part32 = nullptr;
+  bool halves = false; int hk = 0;
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
   int mode = 0;
   int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;
@@ -49,7 +54,9 @@ struct SeedDevice {
 };
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
-                       const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin = 0);
+                       const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin = 0,
+                       const std::vector<std::string> *partners = nullptr, const std::vector<uint8_t> *sides = nullptr,
+                       int halves_k = 0);
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
 void seed_free(SeedDevice *d);
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);

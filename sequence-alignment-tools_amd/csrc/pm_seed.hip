@@ -64,6 +64,9 @@ struct SeedArgs {
   pm_hit *out;
   unsigned long long *counter;
   unsigned long long cap;
+  int halves, hk;                       // exact_halves -k: patterns are halves, partner prefilter for hk edits
+  const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
+  const uint8_t *part_len, *part_side;  // its length; 0 = partner lies to the right of the seed, 1 = to the left
   const SeedArgs *self;                 // device copy of this struct, for the out-of-line rare paths
 };
 
@@ -136,6 +139,39 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h) {
   return (word >> ((h >> 27) & 31)) & (word >> ((h >> 22) & 31)) & (word >> ((h >> 17) & 31)) & 1u;
 }
 
+// exact_halves with edits (-k): the "patterns" are halves and a seed is an exact occurrence of one
+// (reference exact_halves.cc:199-224).  The reference then runs a banded DP of the partner half
+// next to every seed (primer_alignment.cc:568-728) -- 0.4 seeds per base at 10^5 primers.  A DP
+// with <= k edits leaves one of k+1 pieces of the partner untouched, displaced by at most k, so
+// this cheap necessary test on 2-bit packed bases removes >99 % of the seeds on the GPU; only the
+// rest are emitted as seed records for the DP (host stage for now).
+__device__ __forceinline__ bool partner_possible(const SeedArgs &a, int64_t p, uint32_t pi, int L) {
+  const int plen = a.part_len[pi], k = a.hk;
+  const int64_t nominal = a.part_side[pi] ? (p + 1 - L - plen) : (p + 1);
+  const int64_t r0 = nominal - k;
+  const int span = plen + 2 * k;                                   // <= 22 bases
+  if (r0 < 0 || r0 + 24 > a.n) return true;                        // near the stream ends: let the DP decide
+  uint64_t T = 0;                                                   // 2 bits per base, base i of [r0, r0+24) at bits 2i
+  const int sh = a.ascii ? 1 : 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    uint64_t raw = 0;
+    for (int b = 0; b < 8; ++b) raw |= (uint64_t)a.text[r0 + 8 * q + b] << (8 * b);
+    const uint32_t lo = pack4((uint32_t)raw, sh), hi = pack4((uint32_t)(raw >> 32), sh);
+    T |= (uint64_t)(lo | (hi << 8)) << (16 * q);
+  }
+  (void)span;
+  const uint64_t PP = a.part32[pi];
+  for (int t = 0; t <= k; ++t) {
+    const int o = t * plen / (k + 1), len = (t + 1) * plen / (k + 1) - o;
+    const uint64_t mask = (1ull << (2 * len)) - 1ull;
+    const uint64_t piece = (PP >> (2 * o)) & mask;
+    for (int s = -k; s <= k; ++s)
+      if (((T >> (2 * (k + o + s))) & mask) == piece) return true;
+  }
+  return false;
+}
+
 // Third stage, exact part: (window ending at p, pattern pi) already passed the packed-distance
 // test; count mismatches on the raw stream codes (N = mismatch, EOS = reject) and report.
 __device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
@@ -164,6 +200,7 @@ __device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint
   for (int j = 0, t = 0; j < m && t < a.r; ++j)
     if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
   if (first != (((uint64_t)mhi << 32) | mlo)) return;
+  if (a.halves && !partner_possible(a, p, pi, L)) return;
   const unsigned long long o = atomicAdd(a.counter, 1ull);
   if (o < a.cap) {
     pm_hit hh;
@@ -459,7 +496,8 @@ static uint64_t binom(int n, int r) {
 }
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
-                       const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin) {
+                       const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin,
+                       const std::vector<std::string> *partners, const std::vector<uint8_t> *sides, int halves_k) {
   SeedTables &t = *out;
   t = SeedTables();
   t.k = k;
@@ -528,6 +566,16 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   }
   const size_t np = pats.size();
   t.pat40.resize(np); t.pat_len.resize(np); t.pat_id.resize(np); t.pat_codes.assign(np * 32, 0);
+  t.halves = partners != nullptr; t.hk = halves_k;
+  t.part32.assign(np, 0); t.part_len.assign(np, 0); t.part_side.assign(np, 0);
+  if (partners)
+    for (size_t j = 0; j < np; ++j) {
+      const std::string &ps = (*partners)[j];
+      if (ps.size() > 16) return "exact_halves partner longer than 16 characters";
+      uint32_t w2 = 0;
+      for (size_t i = 0; i < ps.size(); ++i) { const int b2 = base2((unsigned char)ps[i]); if (b2 < 0) return "pattern with characters other than A,C,G,T"; w2 |= (uint32_t)b2 << (2 * i); }
+      t.part32[j] = w2; t.part_len[j] = (uint8_t)ps.size(); t.part_side[j] = (*sides)[j];
+    }
   // buckets of 8 slots, average fill <= 3; slot = fingerprint (high bits) | pattern index (low idx_bits)
   int idx_bits = 1;
   while (((size_t)1 << idx_bits) <= np) ++idx_bits;
@@ -607,6 +655,10 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
   if ((e = up(t.pat_codes.data(), t.pat_codes.size(), (void **)&d->pat_codes)) != hipSuccess) return e;
   if ((e = up(t.cmap, 256, (void **)&d->cmap)) != hipSuccess) return e;
+  if ((e = up(t.part32.data(), t.part32.size() * 4, (void **)&d->part32)) != hipSuccess) return e;
+  if ((e = up(t.part_len.data(), t.part_len.size(), (void **)&d->part_len)) != hipSuccess) return e;
+  if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
+  d->halves = t.halves; d->hk = t.hk;
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1>), reinterpret_cast<const void *>(pm_seed_scan<20, 2>),
@@ -617,7 +669,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
 }
 
 void seed_free(SeedDevice *d) {
-  void *ptrs[] = {d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  void *ptrs[] = {d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = SeedDevice();
 }
@@ -657,6 +709,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
   a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
+  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
