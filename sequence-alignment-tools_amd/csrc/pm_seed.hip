@@ -200,7 +200,6 @@ __device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint
   for (int j = 0, t = 0; j < m && t < a.r; ++j)
     if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
   if (first != (((uint64_t)mhi << 32) | mlo)) return;
-  if (a.halves && !partner_possible(a, p, pi, L)) return;
   const unsigned long long o = atomicAdd(a.counter, 1ull);
   if (o < a.cap) {
     pm_hit hh;
@@ -210,14 +209,57 @@ __device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint
   }
 }
 
+// same, for exact_halves -k (patterns are halves): the seed is emitted only if the partner half can match
+__device__ __noinline__ void verify_half(const SeedArgs *ap, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
+  const SeedArgs &a = *ap;
+  const int L = a.pat_len[pi];
+  const int64_t start = p + 1 - L;
+  if (start < 0) return;
+  const uint8_t *pc = a.pat_codes + (size_t)pi * 32;
+  int ham = 0;
+  uint32_t dirty = 0;                                 // pieces (of the last Lw bases) with a mismatch
+  bool left_clean = true, right_clean = true;
+  const int m = a.k + a.r;
+  for (int i = 0; i < L; ++i) {
+    const uint8_t tc = a.text[start + i];
+    if (a.cmap[tc] == 1) return;                      // EOS inside the window: never a candidate
+    if (tc != pc[i]) {
+      if (++ham > a.k) return;
+      if (i < L / 2) left_clean = false; else right_clean = false;
+      const int j = i - (L - a.Lw);                   // position inside the seeded suffix
+      if (j >= 0 && j / a.pb < m) dirty |= 1u << (j / a.pb);
+    }
+  }
+  // report once: only through the combo made of the first r clean pieces
+  uint64_t first = 0;
+  const uint64_t field = (1ull << (2 * a.pb)) - 1ull;
+  for (int j = 0, t = 0; j < m && t < a.r; ++j)
+    if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
+  if (first != (((uint64_t)mhi << 32) | mlo)) return;
+  if (!partner_possible(a, p, pi, L)) return;                   // exact_halves -k: see partner_possible
+  const unsigned long long o = atomicAdd(a.counter, 1ull);
+  if (o < a.cap) {
+    pm_hit hh;
+    hh.end = p + 1; hh.pid = a.pat_id[pi]; hh.k = (uint8_t)ham;
+    hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
+    a.out[o] = hh;
+  }
+}
+
+template <bool HALVES>
+__device__ __forceinline__ void verify_hit(const SeedArgs *ap, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
+  if (HALVES) verify_half(ap, mlo, mhi, p, pi); else verify_exact(ap, mlo, mhi, p, pi);
+}
+
 // packed distance (2 bits per base) never exceeds the true one: a cheap necessary condition
 __device__ __forceinline__ bool packed_close(const uint2 &pp, uint64_t W, int k) {
   const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
   return __popcll((x | (x >> 1)) & 0x5555555555555555ull) <= k;
 }
 
+template <bool HALVES>
 __device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p, uint32_t pi) {
-  if (packed_close(a.pat40[pi], W, a.k)) verify_exact(a.self, mlo, mhi, p, pi);
+  if (packed_close(a.pat40[pi], W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pi);
 }
 
 // slots of a loaded bucket whose fingerprint matches, as a bit mask; bit 8 = the bucket is full
@@ -237,18 +279,20 @@ __device__ __forceinline__ uint32_t match_mask(const uint4 &q0, const uint4 &q1,
 // Second stage.  A 32-byte bucket (two 16-byte loads issued together) holds 8 fingerprinted
 // slots; the probe sequence ends at the first bucket with a free slot, which is almost always the
 // first one.  check_bucket tests the slots of a bucket that is already in registers.
+template <bool HALVES>
 __device__ __forceinline__ bool check_bucket(const SeedArgs &a, const uint4 &q0, const uint4 &q1, uint32_t fp, uint32_t imask,
                                              uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
   const uint32_t sl[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (sl[i] == EMPTY) return true;
-    if ((sl[i] & ~imask) == fp) verify_pattern(a, mlo, mhi, W, p, sl[i] & imask);
+    if ((sl[i] & ~imask) == fp) verify_pattern<HALVES>(a, mlo, mhi, W, p, sl[i] & imask);
   }
   return false;
 }
 
 // continue a probe sequence from bucket b (rare: only after a full bucket)
+template <bool HALVES>
 __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets, uint32_t b, uint32_t fp, uint32_t imask,
                                         uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
   const SeedArgs &a = *ap;
@@ -256,7 +300,7 @@ __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets
   for (;;) {
     b &= bmask;
     const uint4 q0 = buckets[2 * (size_t)b], q1 = buckets[2 * (size_t)b + 1];
-    if (check_bucket(a, q0, q1, fp, imask, mlo, mhi, W, p)) break;
+    if (check_bucket<HALVES>(a, q0, q1, fp, imask, mlo, mhi, W, p)) break;
     ++b;
   }
 }
@@ -264,7 +308,7 @@ __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets
 
 // LW > 0: window length known at compile time (all shifts immediate); LW == 0: taken from a.Lw.
 // MODE: see window_hash.
-template <int LW, int MODE>
+template <int LW, int MODE, bool HALVES>
 __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   uint32_t *bloom = lds;                                          // SEED_BLOOM_WORDS dwords
@@ -370,7 +414,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       if (mm & 511u) {
         const uint64_t W = ((uint64_t)whi << 32) | wlo;
         if (mm & 255u) {
-          if (packed_close(pp, W, a.k)) verify_exact(a.self, mlo, mhi, p, pidx);
+          if (packed_close(pp, W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pidx);
           uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);         // matches beyond the first (rare)
           while (rest) {
             const int sidx = __ffs(rest) - 1;
@@ -378,10 +422,10 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
             uint32_t slot = 0;
 #pragma unroll
             for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
-            verify_pattern(a, mlo, mhi, W, p, slot & imask);
+            verify_pattern<HALVES>(a, mlo, mhi, W, p, slot & imask);
           }
         }
-        if (mm & 256u) probe_from(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
+        if (mm & 256u) probe_from<HALVES>(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
       }
     }
     q2n = 0;
@@ -661,8 +705,9 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   d->halves = t.halves; d->hk = t.hk;
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
-  const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1>), reinterpret_cast<const void *>(pm_seed_scan<20, 2>),
-                           reinterpret_cast<const void *>(pm_seed_scan<20, 0>), reinterpret_cast<const void *>(pm_seed_scan<0, 0>)};
+  const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
+                           reinterpret_cast<const void *>(pm_seed_scan<20, 0, false>), reinterpret_cast<const void *>(pm_seed_scan<0, 0, false>),
+                           reinterpret_cast<const void *>(pm_seed_scan<0, 0, true>)};
   for (const void *kf : kernels)
     if ((e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, SEED_LDS_BYTES)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
@@ -718,10 +763,11 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   hipError_t ce = hipMemcpyAsync(d.d_args, &a, sizeof(a), hipMemcpyHostToDevice, st);
   if (ce != hipSuccess) return ce;
   const dim3 grid(g.blocks), block(SEED_THREADS);
-  if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1>), grid, block, SEED_LDS_BYTES, st, a);
-  else if (d.Lw == 20 && d.mode == 2) hipLaunchKernelGGL((pm_seed_scan<20, 2>), grid, block, SEED_LDS_BYTES, st, a);
-  else if (d.Lw == 20) hipLaunchKernelGGL((pm_seed_scan<20, 0>), grid, block, SEED_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((pm_seed_scan<0, 0>), grid, block, SEED_LDS_BYTES, st, a);
+  if (d.halves) hipLaunchKernelGGL((pm_seed_scan<0, 0, true>), grid, block, SEED_LDS_BYTES, st, a);
+  else if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1, false>), grid, block, SEED_LDS_BYTES, st, a);
+  else if (d.Lw == 20 && d.mode == 2) hipLaunchKernelGGL((pm_seed_scan<20, 2, false>), grid, block, SEED_LDS_BYTES, st, a);
+  else if (d.Lw == 20) hipLaunchKernelGGL((pm_seed_scan<20, 0, false>), grid, block, SEED_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((pm_seed_scan<0, 0, false>), grid, block, SEED_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 
