@@ -94,7 +94,7 @@ def cpu_baseline(args, stream0, primers_fwd, log):
     k, indels = args.k, bool(args.indels)
     sample = args.cpu_sample
     if sample <= 0:
-        sample = {0: 40_000_000, 1: 20_000_000}.get(k, 100_000)     # ~10-30 s of single-thread CPU work
+        sample = {0: 150_000_000, 1: 60_000_000}.get(k, 100_000)     # ~10-30 s of single-thread CPU work
     sample = min(sample, stream0.numel())
     codes = stream0[:sample].cpu().numpy()
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
