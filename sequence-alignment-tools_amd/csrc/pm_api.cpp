@@ -55,6 +55,10 @@ struct pm_handle {
   SeedDevice sd;                      // first pattern tile (plan parameters are read from here)
   std::vector<SeedDevice> sd_more;    // further tiles when the pattern set is too large for one LDS filter
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
+  bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
+  pm_hit *d_ext = nullptr;            // its output (swapped with d_cands after every scan)
+  uint8_t *d_half_codes = nullptr, *d_half_len = nullptr;
+  int32_t *d_hesb = nullptr, *d_heeb = nullptr;
   int scan_k = 0, seed_k = 0;
   bool scan_indels = false;
   pm_hit *d_cands = nullptr;
@@ -159,6 +163,8 @@ static void free_device(pm_handle *h) {
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
   if (h->d_cands) (void)hipFree(h->d_cands);
+  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb}; for (void *q : hx) if (q) (void)hipFree(q); }
+  h->d_ext = nullptr; h->d_half_codes = h->d_half_len = nullptr; h->d_hesb = h->d_heeb = nullptr;
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->h_counter) (void)hipHostFree(h->h_counter);
   if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
@@ -183,6 +189,7 @@ static int ensure_capacity(pm_handle *h, size_t cap, bool exact = false) {
   if (h->d_cands) (void)hipFree(h->d_cands);
   h->d_cands = nullptr;
   HIP_TRY(h, hipMalloc((void **)&h->d_cands, cap * sizeof(pm_hit)));
+  if (h->d_ext) { (void)hipFree(h->d_ext); h->d_ext = nullptr; }
   h->cap = cap;
   return PM_OK;
 }
@@ -339,10 +346,33 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       h->sd.maxlen = mx;
       h->kern = PM_KERNEL_SEED;
       h->seed_flags = h->sem == PM_SEM_EXACT_HALVES && !halves_mode;
+      h->halves_dev = halves_mode;
+      if (halves_mode) {
+        const size_t nh = h->inner.size();
+        std::vector<uint8_t> codes(nh * 16, 0), lens(nh, 0);
+        for (size_t i = 0; i < nh; ++i) {
+          lens[i] = (uint8_t)h->inner[i].s.size();
+          for (size_t q = 0; q < h->inner[i].s.size() && q < 16; ++q) codes[i * 16 + q] = (uint8_t)h->alpha.nch[(unsigned char)h->inner[i].s[q]];
+        }
+        std::vector<int32_t> es(h->pats.size()), ee(h->pats.size());
+        for (size_t i = 0; i < h->pats.size(); ++i) { es[i] = h->pats[i].esb; ee[i] = h->pats[i].eeb; }
+        { void *hx[] = {h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb}; for (void *q : hx) if (q) (void)hipFree(q); }
+        HIP_TRY(h, hipMalloc((void **)&h->d_half_codes, codes.size() ? codes.size() : 16));
+        HIP_TRY(h, hipMalloc((void **)&h->d_half_len, lens.size() ? lens.size() : 16));
+        HIP_TRY(h, hipMalloc((void **)&h->d_hesb, es.size() ? es.size() * 4 : 16));
+        HIP_TRY(h, hipMalloc((void **)&h->d_heeb, ee.size() ? ee.size() * 4 : 16));
+        if (nh) {
+          HIP_TRY(h, hipMemcpy(h->d_half_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+          HIP_TRY(h, hipMemcpy(h->d_half_len, lens.data(), lens.size(), hipMemcpyHostToDevice));
+          HIP_TRY(h, hipMemcpy(h->d_hesb, es.data(), es.size() * 4, hipMemcpyHostToDevice));
+          HIP_TRY(h, hipMemcpy(h->d_heeb, ee.data(), ee.size() * 4, hipMemcpyHostToDevice));
+        }
+      }
       h->seed_k = sk;
     }
   }
   if (!want_seed) {
+    h->halves_dev = false;
     h->kern = PM_KERNEL_BITPAR;
     BitparTables tabs;
     std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs);
@@ -490,6 +520,19 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   if (n_out) *n_out = cnt;
   if (cnt > h->cap) { h->last_count = 0; return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
   h->last_count = cnt;
+  if (h->halves_dev) {
+    // second device pass: banded DP next to every surviving seed (pm_extend.hip); the records
+    // handed on are the successful extensions
+    if (!h->d_ext) HIP_TRY(h, hipMalloc((void **)&h->d_ext, h->cap * sizeof(pm_hit)));
+    HIP_TRY(h, extend_seeds(h->d_text, h->n, h->d_cands, cnt, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb,
+                            h->cfg.k, h->eos_code, h->d_ext, h->d_counter, h->cap, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::swap(h->d_cands, h->d_ext);
+    h->last_count = (size_t)*h->h_counter;
+    if (n_out) *n_out = h->last_count;
+    h->last_launches += 1;
+  }
   if (h->kern == PM_KERNEL_SEED && h->scan_begin == 0 && h->seed_k > 0 &&
       (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT)) {
     int rc = stream_start_candidates(h);
@@ -760,6 +803,25 @@ int finalize_halves_flags(pm_handle *h, const pm_hit *cands, size_t n, int64_t s
   return PM_OK;
 }
 
+// exact_halves -k with the extension done on the GPU (pm_extend.hip): records are
+// {end = seed position, pid = inner id, k = value, aux[0] = hit end - seed position}.  What is left
+// is the reference's sequential rule (exact_halves.cc:142,163,178): seeds in (position asc, inner id
+// desc) order, a hit is kept if its end exceeds the pattern's last kept end by more than 2k.
+int finalize_extended(pm_handle *h, const pm_hit *cands, size_t n, std::vector<pm_hit> &outv) {
+  std::vector<pm_hit> seeds(cands, cands + n);
+  std::sort(seeds.begin(), seeds.end(), seed_order);
+  const int slack = h->cfg.indels ? 2 * h->cfg.k : 0;
+  for (const pm_hit &s : seeds) {
+    const uint32_t j = (s.pid + 1) / 2;
+    const int64_t end = s.end + s.aux[0];
+    if (end > h->lasthit[j] + slack) {
+      outv.push_back(make_hit(end, h->pats[j - 1].id, s.k));
+      h->lasthit[j] = end;
+    }
+  }
+  return PM_OK;
+}
+
 }  // namespace
 
 static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
@@ -770,7 +832,10 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
       outv.insert(outv.end(), cands, cands + n);
       break;
     case PM_SEM_FILTER_BITVEC: rc = finalize_filter_bitvec(h, cands, n, scanned_to, last, outv); break;
-    case PM_SEM_EXACT_HALVES: rc = h->seed_flags ? finalize_halves_flags(h, cands, n, scanned_to, last, outv) : finalize_seeds(h, cands, n, true, outv); break;
+    case PM_SEM_EXACT_HALVES:
+      rc = h->seed_flags ? finalize_halves_flags(h, cands, n, scanned_to, last, outv)
+         : h->halves_dev ? finalize_extended(h, cands, n, outv) : finalize_seeds(h, cands, n, true, outv);
+      break;
     case PM_SEM_EXACT_BASES: rc = finalize_seeds(h, cands, n, false, outv); break;
     default: return fail(h, PM_E_INVALID, "finalize: bad semantics");
   }

@@ -80,4 +80,10 @@ hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_t
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
 
+
+// ---- seed extension DP on the GPU (pm_extend.hip) ---------------------------------------------
+hipError_t extend_seeds(const uint8_t *d_text, int64_t n, const pm_hit *d_seeds, size_t nseeds,
+                        const uint8_t *d_half_codes, const uint8_t *d_half_len, const int32_t *d_esb, const int32_t *d_eeb,
+                        int k, int eos_code, pm_hit *d_out, unsigned long long *d_counter, size_t cap, hipStream_t st);
+
 }  // namespace pm
