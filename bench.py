@@ -10,7 +10,7 @@ cluster/verify on rank 0 -> final hits resident on the host of rank 0.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 The database is sharded by stream position across ranks: rank r holds and scans
-stream range [r*S, (r+1)*S) plus a 256-byte halo on its left; every rank holds all patterns.
+stream range [r*S, (r+1)*S) plus a 256-byte halo on either side; every rank holds all patterns.
 Default scaling is weak (S = --db-bases per GPU, the 3 Gbp configuration per GPU);
 --scaling strong splits a fixed --db-bases database over the ranks.
 Prints ONE JSON line on rank 0.
@@ -184,7 +184,8 @@ def main():
     shard = (total + world - 1) // world
     lo, hi = rank * shard, min(total, (rank + 1) * shard)
     glo = max(0, lo - HALO)
-    stream = gen_stream(glo, hi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev)
+    ghi = min(total, hi + HALO)          # right halo: seed extensions (-k) read up to len+k bytes past a shard's end
+    stream = gen_stream(glo, ghi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev)
     n_bases_total = total - (args.entries * (world if args.scaling == "weak" else 1) + 1)
     if rank == 0:
         primers = make_primers(stream[:min(stream.numel(), 1 << 26)], args.primers, args.length, 7)
@@ -226,8 +227,8 @@ def main():
                 if e.code != -2:
                     raise
                 dev_final[0] = False
-        if world > 1 and pm.selected()[0] == sat_amd.SEM_EXACT_HALVES and args.indels:
-            raise SystemExit("bench.py --gpus>1: -k with exact_halves needs stream text in the verify stage (DESIGN.md 5)")
+        if world > 1 and pm.selected()[1] == sat_amd.KERNEL_BITPAR and pm.selected()[0] in (sat_amd.SEM_EXACT_HALVES, sat_amd.SEM_EXACT_BASES, sat_amd.SEM_FILTER_BITVEC) and args.indels:
+            raise SystemExit("bench.py --gpus>1: this option set verifies on the host with stream text, which rank 0 does not hold (DESIGN.md 5)")
         cands = np.zeros(cnt, dtype=sat_amd.HIT_DTYPE)
         if cnt:
             cands = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).cpu().numpy().view(sat_amd.HIT_DTYPE)
