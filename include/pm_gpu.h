@@ -65,7 +65,7 @@ typedef enum {
 /* Which kernel family computes it (the "-N 16 / -N 17" of INTEGRATION.md). */
 typedef enum {
   PM_KERNEL_AUTO = 0,
-  PM_KERNEL_BITPAR = 16,   /* bit-parallel Shift-And / Wu-Manber rows, any alphabet with <= 4 pattern codes */
+  PM_KERNEL_BITPAR = 16,   /* bit-parallel Shift-And / Wu-Manber rows, any alphabet, <= 6 accepted stream codes */
   PM_KERNEL_SEED = 17      /* 2-bit packed k-mer seeds (LDS filter) + verify; A,C,G,T patterns <= 32 nt */
 } pm_kernel;
 
@@ -77,8 +77,8 @@ typedef struct {
   int32_t kernel;          /* pm_kernel */
   int32_t k;               /* -k / -K value */
   int32_t indels;          /* 1 = -k (edits), 0 = -K (substitutions only) */
-  int32_t wildcards;       /* -w/-W: must be 0 (PM_E_UNSUPPORTED otherwise) */
-  int32_t text_n;
+  int32_t wildcards;       /* -w/-W: IUPAC pattern classes; exact search only (k > 0: PM_E_UNSUPPORTED) */
+  int32_t text_n;          /* -W: a text N also matches (shift_and.cc:112) */
   int32_t eos;             /* raw end-of-sequence char, '\n' in the CLIs */
   int32_t device;          /* HIP device ordinal */
   int32_t reserved[7];

@@ -73,6 +73,25 @@ typedef struct {
  * (shift_and_inexact.cc:90-220), literal patterns only (no -w classes, no regex classes):
  * pattern j occupies bits [sum len<j, sum len<=j) of one long bit string; u[c] has a bit set
  * where the pattern char's code is c; s marks first chars, last marks last chars. */
+/* iupac_compatible(w) of the reference (util.cc:121-162), as data */
+static const char *iupac_set(unsigned char w) {
+  switch (w) {
+    case 'A': return "ARMWDHVN"; case 'B': return "GTUCYKSBN"; case 'C': return "CYMSBHVN"; case 'D': return "GATURWKDN";
+    case 'G': return "GRKSBDVN"; case 'H': return "ACTUMYWHN"; case 'K': return "GTKBDN"; case 'M': return "ACMHVN";
+    case 'N': return "ACGTURYKMSWVDHVN"; case 'R': return "GARDVN"; case 'S': return "GCSBVN"; case 'T': return "TUYKWVDHN";
+    case 'U': return "UTYKWVDHN"; case 'V': return "GCARSMVN"; case 'W': return "ATUWDHN"; case 'Y': return "TUCYBHN";
+    case 'X': return "MRWSYKVHDBXN";
+    case 'a': return "armwdhvn"; case 'b': return "gtucyksbn"; case 'c': return "cymsbhvn"; case 'd': return "gaturwkdn";
+    case 'g': return "grksbdvn"; case 'h': return "actumywhn"; case 'k': return "gtkbdn"; case 'm': return "acmhvn";
+    case 'n': return "acgturykmswvdhvn"; case 'r': return "gardvn"; case 's': return "gcsbvn"; case 't': return "tuykwvdhn";
+    case 'u': return "utykwvdhn"; case 'v': return "gcarsmvn"; case 'w': return "atuwdhn"; case 'y': return "tucybhn";
+    case 'x': return "mrwsykvhdbxn";
+  }
+  return 0;
+}
+
+static int g_wc = 0, g_tn = 0;   /* -w / -W for the mask build of the current pmo_find_all call */
+
 static int build_masks(bitmasks *m, const pmo_text *t, const pat_t *p, int np) {
   int64_t bits = 0;
   for (int j = 0; j < np; j++) bits += p[j].len;
@@ -87,8 +106,16 @@ static int build_masks(bitmasks *m, const pmo_text *t, const pat_t *p, int np) {
   int64_t b = 0;
   for (int j = 0; j < np; j++) {
     for (int i = 0; i < p[j].len; i++, b++) {
-      int code = t->nch[(uint8_t)p[j].s[i]];
-      if (code >= 0 && code < m->A) m->u[(size_t)code * m->W + (b >> 6)] |= 1ULL << (b & 63);
+      const char *set = g_wc ? iupac_set((uint8_t)p[j].s[i]) : 0;      /* shift_and.cc:108-117 */
+      if (set) {
+        for (const char *q = set; *q; ++q) {
+          int c1 = t->nch[(uint8_t)*q];
+          if (c1 >= 0 && c1 < m->A && (*q != 'N' || g_tn)) m->u[(size_t)c1 * m->W + (b >> 6)] |= 1ULL << (b & 63);
+        }
+      } else {
+        int code = t->nch[(uint8_t)p[j].s[i]];
+        if (code >= 0 && code < m->A) m->u[(size_t)code * m->W + (b >> 6)] |= 1ULL << (b & 63);
+      }
       if (i == 0) m->s[b >> 6] |= 1ULL << (b & 63);
       if (i == p[j].len - 1) { m->last[b >> 6] |= 1ULL << (b & 63); m->endbit[j] = (int)b; }
     }
@@ -688,7 +715,8 @@ int pmo_pick_engine(const pmo_text *t, int k, int indels, int wildcards, int npa
 int pmo_find_all(const pmo_text *t, const pmo_config *cfg,
                  const char *patbuf, const int64_t *patoff, int npat, const uint32_t *ids,
                  const int32_t *esb, const int32_t *eeb, pmo_hit **out, size_t *nout) {
-  if (cfg->wildcards) return -3;
+  if (cfg->wildcards && (cfg->k > 0 || (cfg->engine != PMO_SHIFT_AND && cfg->engine != PMO_AUTO))) return -3;   /* -w: exact shift_and only */
+  g_wc = cfg->wildcards; g_tn = cfg->text_n;
   pat_t *p = (pat_t *)malloc(sizeof(pat_t) * (size_t)(npat ? npat : 1));
   int32_t *plen = (int32_t *)malloc(sizeof(int32_t) * (size_t)(npat ? npat : 1));
   if (!p || !plen) return -1;

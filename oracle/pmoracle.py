@@ -80,16 +80,16 @@ def _pack(patterns):
     return buf, off
 
 
-def _cfg(engine, k, indels, eos):
+def _cfg(engine, k, indels, eos, wildcards=False, text_n=False):
     c = _Config()
-    c.engine, c.k, c.indels, c.wildcards, c.text_n, c.eos = engine, k, int(bool(indels)), 0, 0, eos
+    c.engine, c.k, c.indels, c.wildcards, c.text_n, c.eos = engine, k, int(bool(indels)), int(bool(wildcards)), int(bool(text_n)), eos
     return c
 
 
-def find_all(text, patterns, engine=AUTO, k=0, indels=True, eos=10, ids=None, esb=None, eeb=None):
+def find_all(text, patterns, engine=AUTO, k=0, indels=True, eos=10, ids=None, esb=None, eeb=None, wildcards=False, text_n=False):
     """All hits of one engine over the whole text, as a structured array in emission order."""
     buf, off = _pack(patterns)
-    cfg = _cfg(engine, k, indels, eos)
+    cfg = _cfg(engine, k, indels, eos, wildcards, text_n)
     out = C.c_void_p()
     n = C.c_size_t()
     a = lambda x, dt: None if x is None else np.ascontiguousarray(x, dtype=dt)

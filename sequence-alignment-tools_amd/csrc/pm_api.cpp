@@ -137,7 +137,8 @@ extern "C" int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized,
 extern "C" int pm_create(const pm_config *cfg, pm_handle **out) {
   if (!cfg || !out) return fail(nullptr, PM_E_INVALID, "pm_create: null argument");
   if (cfg->abi_version != PM_ABI_VERSION) return fail(nullptr, PM_E_INVALID, "pm_create: ABI version mismatch");
-  if (cfg->wildcards) return fail(nullptr, PM_E_UNSUPPORTED, "IUPAC wildcard matching (-w/-W) is not implemented yet");
+  if (cfg->wildcards && cfg->k > 0)
+    return fail(nullptr, PM_E_UNSUPPORTED, "IUPAC wildcard matching (-w/-W) is implemented for exact search (k = 0) only");
   if (cfg->k < 0) return fail(nullptr, PM_E_INVALID, "pm_create: negative k");
   pm_handle *h = new (std::nothrow) pm_handle();
   if (!h) return fail(nullptr, PM_E_NOMEM, "out of memory");
@@ -260,6 +261,7 @@ static int resolve(pm_handle *h) {
 // rules are then applied to (end, pattern, distance, clean-half flags) records on the host.
 static bool seed_eligible(pm_handle *h, std::string *why) {
   const int sem = h->sem;
+  if (h->cfg.wildcards) { *why = "IUPAC wildcards run on the bit-parallel family"; return false; }
   if (h->cfg.k > 0 && h->cfg.indels && sem == PM_SEM_EXACT_HALVES) {
     // exact_halves with edits: exact seeds of the halves + partner prefilter on the GPU, DP on the host
     if (h->cfg.k > 2) { *why = "exact_halves -k > 2 runs on the bit-parallel family"; return false; }
@@ -375,7 +377,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     h->halves_dev = false;
     h->kern = PM_KERNEL_BITPAR;
     BitparTables tabs;
-    std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs);
+    std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs,
+                                   h->cfg.wildcards != 0, h->cfg.text_n != 0);
     if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine: " + msg);
     HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
   }

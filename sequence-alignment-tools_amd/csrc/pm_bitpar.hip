@@ -23,6 +23,7 @@
 // Cost model: 4 VALU ops per (dword, character) exact, 10 for k=2 substitutions, 19 for k=2
 // edits -> integer-ALU bound (DESIGN.md "bitpar roofline"); HBM traffic is negligible.
 #include "pm_internal.h"
+#include "pm_iupac.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256) void pm_bitpar_scan(BitparArgs a) {
           case 1: step<K, INDELS, true>(R, u[1], s); break;
           case 2: step<K, INDELS, true>(R, u[2], s); break;
           case 3: step<K, INDELS, true>(R, u[3], s); break;
+          case 4: step<K, INDELS, true>(R, u[4], s); break;
+          case 5: step<K, INDELS, true>(R, u[5], s); break;
           case BP_NC: step<K, INDELS, false>(R, zero, s); break;
           default: clear_rows<K>(R); break;               // EOS code
         }
@@ -209,7 +212,27 @@ const char *bitpar_kernel_name(int k, bool indels) {
 }
 
 std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
-                         const Alphabet &alpha, int k, int eos_code, BitparTables *out) {
+                         const Alphabet &alpha, int k, int eos_code, BitparTables *out, bool wildcards, bool text_n) {
+  // stream codes a pattern character accepts: itself, or with -w/-W every letter of its IUPAC
+  // compatibility set that exists in the stream alphabet, text N only with -W (shift_and.cc:108-147)
+  auto accepted = [&](unsigned char ch, int *codes) -> int {
+    int nc = 0;
+    const char *set = wildcards ? iupac_compatible_set(ch) : nullptr;
+    if (set) {
+      for (const char *q = set; *q; ++q) {
+        const int code = alpha.nch[(unsigned char)*q];
+        if (code >= 0 && code < alpha.size && (*q != 'N' || text_n)) {
+          bool dup = false;
+          for (int i = 0; i < nc; ++i) dup = dup || codes[i] == code;
+          if (!dup) codes[nc++] = code;
+        }
+      }
+    } else {
+      const int code = alpha.nch[ch];
+      if (code >= 0 && code < alpha.size) codes[nc++] = code;
+    }
+    return nc;
+  };
   BitparTables &t = *out;
   t = BitparTables();
   t.k = k;
@@ -222,13 +245,14 @@ std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uin
     if ((int)p.s.size() > 32 * BP_WPL) return "pattern longer than 256 characters";
     t.maxlen = std::max(t.maxlen, (int)p.s.size());
     for (unsigned char ch : p.s) {
-      const int code = alpha.nch[ch];
-      if (code < 0 || code >= alpha.size) continue;       // never matches (shift_and.cc:143: nch < 0)
-      if (cls_of_code[code] < 0) {
-        if (t.nclasses == BP_NC) return "patterns use more than 4 distinct stream codes";
-        cls_of_code[code] = t.nclasses;
-        t.cmap[code] = (uint8_t)t.nclasses++;
-      }
+      int codes[32];
+      const int nc = accepted(ch, codes);                  // none: never matches (shift_and.cc:143: nch < 0)
+      for (int q = 0; q < nc; ++q)
+        if (cls_of_code[codes[q]] < 0) {
+          if (t.nclasses == BP_NC) return "patterns accept more than 6 distinct stream codes";
+          cls_of_code[codes[q]] = t.nclasses;
+          t.cmap[codes[q]] = (uint8_t)t.nclasses++;
+        }
     }
   }
   if (eos_code >= 0 && eos_code < 256) {
@@ -264,8 +288,9 @@ std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uin
       for (int i = 0; i < L; ++i) {
         const int b = slot[j].bit + i, w = b >> 5;
         const uint32_t m = 1u << (b & 31);
-        const int code = alpha.nch[(unsigned char)p.s[i]];
-        if (code >= 0 && code < alpha.size) t.U[((tile * BP_NC + cls_of_code[code]) * W + w) * 64 + l64] |= m;
+        int codes[32];
+        const int nc = accepted((unsigned char)p.s[i], codes);
+        for (int q = 0; q < nc; ++q) t.U[((tile * BP_NC + cls_of_code[codes[q]]) * W + w) * 64 + l64] |= m;
         if (i == 0) t.S[(tile * W + w) * 64 + l64] |= m;
         if (i == L - 1) t.LAST[(tile * W + w) * 64 + l64] |= m;
         for (int l = i + 1; l <= k; ++l) t.INIT[((tile * k + (l - 1)) * W + w) * 64 + l64] |= m;

@@ -28,7 +28,7 @@ struct Alphabet {
 
 // ---- bit-parallel family (pm_bitpar.hip) -----------------------------------------------------
 constexpr int BP_WPL = 8;          // 32-bit words per lane: a lane holds a 256-bit pattern string
-constexpr int BP_NC = 4;           // distinct text codes the patterns may use (A,C,G,T)
+constexpr int BP_NC = 6;           // distinct stream codes the patterns may accept (A,C,G,T,N + one)
 constexpr int BP_BLOCK = 256;      // text bytes per block step (64 lanes x 4 bytes)
 
 struct BitparTables {              // host-built, then uploaded
@@ -54,7 +54,8 @@ struct BitparDevice {
 
 // Build the packed tables.  Returns "" or an error message (PM_E_UNSUPPORTED).
 std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
-                         const Alphabet &alpha, int k, int eos_code, BitparTables *out);
+                         const Alphabet &alpha, int k, int eos_code, BitparTables *out,
+                         bool wildcards = false, bool text_n = false);
 hipError_t bitpar_upload(const BitparTables &t, bool indels, BitparDevice *d, hipStream_t st);
 void bitpar_free(BitparDevice *d);
 

@@ -115,11 +115,12 @@ class PatternMatch:
     (-N), SEM_AUTO reproduces the automatic choice; `kernel` picks the GPU kernel family.
     """
 
-    def __init__(self, k=0, indels=True, eos="\n", semantics=SEM_AUTO, kernel=KERNEL_AUTO, device=0):
+    def __init__(self, k=0, indels=True, eos="\n", semantics=SEM_AUTO, kernel=KERNEL_AUTO, device=0,
+                 wildcards=False, text_n=False):
         self._L = load_library()
         cfg = _Config()
         cfg.abi_version, cfg.semantics, cfg.kernel, cfg.k = 1, semantics, kernel, k
-        cfg.indels, cfg.wildcards, cfg.text_n = int(bool(indels)), 0, 0
+        cfg.indels, cfg.wildcards, cfg.text_n = int(bool(indels)), int(bool(wildcards)), int(bool(text_n))
         cfg.eos = ord(eos) if isinstance(eos, str) else int(eos)
         cfg.device = device
         self._h = C.c_void_p()

@@ -261,3 +261,33 @@ def test_pattern_tiling_gives_identical_hits(monkeypatch):
         many = sat_amd.sorted_tuples(pm.find_all())
         pm.close()
         assert many == one and len(one) > 0, (k, ind)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_iupac_wildcards_exact(seed):
+    """-w / -W exact search (shift_and with IUPAC classes) on the bit-parallel family vs the oracle;
+    k > 0 with wildcards is refused, not approximated."""
+    rng = np.random.default_rng(800 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(500, 3000)), n_runs=5, repeats=(seed % 2 == 0))
+    L = int(rng.integers(8, 14))
+    pats = []
+    for p in synth.make_patterns(rng, ents, int(rng.integers(10, 80)), length=L, planted=0.9, indel_frac=0.0, extras=False):
+        p = list(p)
+        for _ in range(int(rng.integers(0, 3))):
+            p[int(rng.integers(0, len(p)))] = str(rng.choice(list("RYKMSWBDHVN")))
+        pats.append("".join(p))
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    for tn in (False, True):
+        want = O.sorted_tuples(O.find_all(text, pats, engine=4, k=0, wildcards=True, text_n=tn))
+        pm = sat_amd.PatternMatch(k=0, wildcards=True, text_n=tn)
+        for i, p in enumerate(pats):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        assert pm.selected() == (sat_amd.SEM_SHIFT_AND, sat_amd.KERNEL_BITPAR)
+        got = sat_amd.sorted_tuples(pm.find_all())
+        pm.close()
+        assert got == want and len(want) > 0, (seed, tn, len(want), len(got))
+    with pytest.raises(sat_amd.PmError):
+        sat_amd.PatternMatch(k=1, wildcards=True)

@@ -60,3 +60,32 @@ def test_fuzz_constraints_against_reference(ref_harness, seed):
                 eng = sel if sel else O.pick_engine(text, allp, k, bool(ind), E, F)
                 got = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=bool(ind), esb=E, eeb=F))
                 assert got == ref, (seed, esb, eeb, sel, k, ind)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_fuzz_wildcards_against_reference(ref_harness, seed):
+    """-w / -W: shift_and with IUPAC pattern classes (shift_and.cc:108-117)."""
+    import os, subprocess, tempfile
+    rng = np.random.default_rng(700 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(300, 2000)), n_runs=4, repeats=(seed % 2 == 0))
+    L = int(rng.integers(8, 14))
+    pats = []
+    for p in synth.make_patterns(rng, ents, int(rng.integers(5, 40)), length=L, planted=0.9, indel_frac=0.0, extras=False):
+        p = list(p)
+        for _ in range(int(rng.integers(0, 3))):
+            p[int(rng.integers(0, len(p)))] = str(rng.choice(list("RYKMSWBDHVN")))
+        pats.append("".join(p))
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "db.sqn"), "wb").write(codes.tobytes())
+        open(os.path.join(d, "db.tbl"), "wb").write(table)
+        open(os.path.join(d, "pat.txt"), "w").write("\n".join(pats) + "\n")
+        for flag, tn in (("-w", False), ("-W", True)):
+            out = subprocess.run([ref_harness, "-N", "4", flag, "-n", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt")],
+                                 capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr[-300:]
+            ref = sorted(tuple(int(x) for x in l.split()) for l in out.stdout.splitlines() if not l.startswith("#"))
+            got = O.sorted_tuples(O.find_all(text, pats, engine=4, k=0, wildcards=True, text_n=tn))
+            assert got == ref, (seed, flag)
