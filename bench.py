@@ -128,6 +128,15 @@ def cpu_baseline(args, stream0, primers_fwd, log):
                       % (sample, len(primers_fwd), dt)}
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "Gbases/s scanned, 100k\u00d720-mer primers k\u22642, 3 Gbp DB at 1/2/4/8 GPUs"
+
+
 def measured_traffic(args, shard):
     """HBM/fabric bytes per launch of the scan kernel from the committed PMC passes
     (profiles/traffic_r*.json, produced by scripts/profile_round.sh), or None when this exact
@@ -292,7 +301,7 @@ def main():
         achieved = alg_bytes / (kms * 1e-3) / 1e9
         desc = pm.describe()
         res = {
-            "metric": "Gbases/s scanned, 100k x 20-mer primers k<=2, 3 Gbp DB",
+            "metric": baseline_metric(),
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
