@@ -155,8 +155,8 @@ __device__ __forceinline__ bool partner_possible(const SeedArgs &a, int64_t p, u
   const int sh = a.ascii ? 1 : 0;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    uint64_t raw = 0;
-    for (int b = 0; b < 8; ++b) raw |= (uint64_t)a.text[r0 + 8 * q + b] << (8 * b);
+    uint64_t raw;
+    __builtin_memcpy(&raw, a.text + r0 + 8 * q, 8);                 // unaligned 8-byte load
     const uint32_t lo = pack4((uint32_t)raw, sh), hi = pack4((uint32_t)(raw >> 32), sh);
     T |= (uint64_t)(lo | (hi << 8)) << (16 * q);
   }
