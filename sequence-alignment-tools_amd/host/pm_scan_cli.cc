@@ -2,6 +2,8 @@
 // (primer_match.cc:1101-1118): prints one line "<end> <id> <errors>" per engine hit.
 //   pm_scan_cli [-N 16|17] [-k edits | -K mismatches] [-r] [-n] [-m minka] [-c chunk] -i <db> -P <patterns>
 //   -n: <db>.sqn + <db>.tbl (normalized stream), otherwise <db> is a raw byte stream.
+//   -B: hide the contiguous buffer (like the reference's -B / BufferedFileChars, char_io.h:172):
+//       the engine then drains the stream through getnch() once.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -10,6 +12,14 @@
 #include <unistd.h>
 
 #include "gpu_pattern_match.h"
+
+// a producer without c_str(): what BufferedFileChars is to the reference engines
+class StreamOnlyChars : public pmgpu::BufferChars {
+ public:
+  using pmgpu::BufferChars::BufferChars;
+  bool has_filename() const override { return false; }
+  const char *c_str() const override { return nullptr; }
+};
 
 static std::string revcomp(const std::string &s) {           // A,C,G,T only (util.cc:374)
   std::string r(s.rbegin(), s.rend());
@@ -26,16 +36,17 @@ static std::vector<unsigned char> slurp(const std::string &path) {
 int main(int argc, char **argv) {
   int kernel = PM_KERNEL_AUTO, k = 0, minka = 1000;
   long chunk = 0;
-  bool indels = true, rc = false, norm = false;
+  bool indels = true, rc = false, norm = false, buffered = false;
   std::string db, patfile;
   int c;
-  while ((c = getopt(argc, argv, "N:k:K:rnm:c:i:P:")) != -1) {
+  while ((c = getopt(argc, argv, "N:k:K:rnBm:c:i:P:")) != -1) {
     switch (c) {
       case 'N': kernel = atoi(optarg); break;
       case 'k': k = atoi(optarg); indels = true; break;
       case 'K': k = atoi(optarg); indels = false; break;
       case 'r': rc = true; break;
       case 'n': norm = true; break;
+      case 'B': buffered = true; break;
       case 'm': minka = atoi(optarg); break;
       case 'c': chunk = atol(optarg); break;
       case 'i': db = optarg; break;
@@ -50,7 +61,9 @@ int main(int argc, char **argv) {
   std::vector<unsigned char> bytes;
   if (norm) { bytes = slurp(db + ".sqn"); auto t = slurp(db + ".tbl"); table.assign(t.begin(), t.end()); }
   else bytes = slurp(db);
-  pmgpu::BufferChars ff(std::move(bytes), table);
+  pmgpu::BufferChars mapped(bytes, table);
+  StreamOnlyChars streamed(bytes, table);
+  pmgpu::CharacterProducer &ff = buffered ? static_cast<pmgpu::CharacterProducer &>(streamed) : mapped;
   pmgpu::GpuPatternMatch kt(kernel, (unsigned)k, '\n', false, false, indels, false);
   if (chunk > 0) kt.chunk_bytes(chunk);
   const size_t n = pats.size();

@@ -38,7 +38,7 @@ def test_cli_matches_reference(case):
     for name, extra in [("auto_k0", []), ("auto_K1", ["-K", "1"]), ("auto_k1", ["-k", "1"]), ("auto_K2", ["-K", "2"]),
                         ("auto_k2", ["-k", "2"])]:
         want = [tuple(h) for h in c["engine"][name]["hits"]]
-        for more in ([], ["-m", "7", "-c", "1500"], ["-N", "16"]):
+        for more in ([], ["-m", "7", "-c", "1500"], ["-N", "16"], ["-B", "-m", "50"]):
             got, _ = run_cli(codes, table, c["patterns"], extra + more)
             assert got == want, (case, name, more)
 
