@@ -314,7 +314,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     size_t tile_keys = 262144;
     if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
     const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
-    const size_t per = (sp.size() + ntile - 1) / ntile;
+    size_t per = (sp.size() + ntile - 1) / ntile;
+    if (halves_mode) per += per & 1;                // keep (left, right) half pairs together: side = index parity
     // the plan (window, pieces) must be the same for every tile: it depends on the shortest pattern
     // of the whole set, so every tile is built with that window forced
     int force_lw = 0;

@@ -117,6 +117,7 @@ __global__ void pm_seed_extend(ExtendArgs a) {
   if (i >= a.nseeds) return;
   const pm_hit s = a.seeds[i];
   const uint32_t hid = s.pid;                                     // 1-based inner id
+  if (hid == PM_SEED_HOLE) return;                                // unused slot of a reserved output block (pm_seed.hip)
   const uint32_t j = (hid - 1) >> 1;
   const bool left = (hid & 1u) != 0;
   const int len1 = a.half_len[2 * j], len2 = a.half_len[2 * j + 1];

@@ -65,6 +65,8 @@ struct SeedArgs {
   unsigned long long *counter;
   unsigned long long cap;
   int halves, hk;                       // exact_halves -k: patterns are halves, partner prefilter for hk edits
+  int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
+                                        // partner's stream window is known before the half's record is read
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
   const uint8_t *part_len, *part_side;  // its length; 0 = partner lies to the right of the seed, 1 = to the left
   const SeedArgs *self;                 // device copy of this struct, for the out-of-line rare paths
@@ -145,23 +147,46 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h) {
 // with <= k edits leaves one of k+1 pieces of the partner untouched, displaced by at most k, so
 // this cheap necessary test on 2-bit packed bases removes >99 % of the seeds on the GPU; only the
 // rest are emitted as seed records for the DP (host stage for now).
-__device__ __forceinline__ bool partner_possible(const SeedArgs &a, int64_t p, uint32_t pi, int L) {
-  const int plen = a.part_len[pi], k = a.hk;
-  const int64_t nominal = a.part_side[pi] ? (p + 1 - L - plen) : (p + 1);
-  const int64_t r0 = nominal - k;
-  const int span = plen + 2 * k;                                   // <= 22 bases
-  if (r0 < 0 || r0 + 24 > a.n) return true;                        // near the stream ends: let the DP decide
-  uint64_t T = 0;                                                   // 2 bits per base, base i of [r0, r0+24) at bits 2i
+__device__ __forceinline__ int64_t partner_window(int64_t p, int total, int side, int k) {
+  // first base of the 24-base stream window the partner test looks at (total = half + partner length)
+  return (side ? (p + 1 - total) : (p + 1)) - k;
+}
+
+__device__ __forceinline__ bool partner_possible(const SeedArgs &a, int plen, uint32_t part, uint64_t raw0, uint64_t raw1, uint64_t raw2) {
+  const int k = a.hk;
+  uint64_t T = 0;                                                   // 2 bits per base, base i of the window at bits 2i
   const int sh = a.ascii ? 1 : 0;
+  const uint64_t raws[3] = {raw0, raw1, raw2};
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    uint64_t raw;
-    __builtin_memcpy(&raw, a.text + r0 + 8 * q, 8);                 // unaligned 8-byte load
-    const uint32_t lo = pack4((uint32_t)raw, sh), hi = pack4((uint32_t)(raw >> 32), sh);
+    const uint32_t lo = pack4((uint32_t)raws[q], sh), hi = pack4((uint32_t)(raws[q] >> 32), sh);
     T |= (uint64_t)(lo | (hi << 8)) << (16 * q);
   }
-  (void)span;
-  const uint64_t PP = a.part32[pi];
+  // piece t of the partner = bases [t*plen/(k+1), (t+1)*plen/(k+1)); it sits unedited at displacement s
+  // iff the XOR of the stream (shifted by k+s bases) with the partner is zero over the piece's bits
+  auto low = [](int bases) -> uint32_t { return bases >= 16 ? 0xffffffffu : ((1u << (2 * bases)) - 1u); };
+  if (k == 1) {
+    const uint32_t m0 = low(plen >> 1), m1 = low(plen) & ~m0;
+    bool ok = false;
+#pragma unroll
+    for (int s = 0; s <= 2; ++s) {
+      const uint32_t x = (uint32_t)(T >> (2 * s)) ^ part;
+      ok = ok || (x & m0) == 0 || (x & m1) == 0;
+    }
+    return ok;
+  }
+  if (k == 2) {
+    const int e0 = plen / 3, e1 = 2 * plen / 3;
+    const uint32_t m0 = low(e0), m1 = low(e1) & ~m0, m2 = low(plen) & ~low(e1);
+    bool ok = false;
+#pragma unroll
+    for (int s = 0; s <= 4; ++s) {
+      const uint32_t x = (uint32_t)(T >> (2 * s)) ^ part;
+      ok = ok || (x & m0) == 0 || (x & m1) == 0 || (x & m2) == 0;
+    }
+    return ok;
+  }
+  const uint64_t PP = part;
   for (int t = 0; t <= k; ++t) {
     const int o = t * plen / (k + 1), len = (t + 1) * plen / (k + 1) - o;
     const uint64_t mask = (1ull << (2 * len)) - 1ull;
@@ -209,46 +234,71 @@ __device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint
   }
 }
 
-// same, for exact_halves -k (patterns are halves): the seed is emitted only if the partner half can match
-__device__ __noinline__ void verify_half(const SeedArgs *ap, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
-  const SeedArgs &a = *ap;
-  const int L = a.pat_len[pi];
-  const int64_t start = p + 1 - L;
-  if (start < 0) return;
-  const uint8_t *pc = a.pat_codes + (size_t)pi * 32;
-  int ham = 0;
-  uint32_t dirty = 0;                                 // pieces (of the last Lw bases) with a mismatch
-  bool left_clean = true, right_clean = true;
-  const int m = a.k + a.r;
-  for (int i = 0; i < L; ++i) {
-    const uint8_t tc = a.text[start + i];
-    if (a.cmap[tc] == 1) return;                      // EOS inside the window: never a candidate
-    if (tc != pc[i]) {
-      if (++ham > a.k) return;
-      if (i < L / 2) left_clean = false; else right_clean = false;
-      const int j = i - (L - a.Lw);                   // position inside the seeded suffix
-      if (j >= 0 && j / a.pb < m) dirty |= 1u << (j / a.pb);
+// exact_halves -k, one seed (half pi ends at p).  Record of a half (seed_build), 32 bytes:
+// codes right-aligned in bytes [16-L, 16) | partner 2-bit | L, partner length, side | inner id.
+// th0/th1 = stream bytes [p-15, p-8], [p-7, p]: the half matches iff its codes equal the last L of
+// them (codes are all A,C,G,T, so N and EOS inside the window reject by themselves).
+__device__ __forceinline__ bool half_codes_equal(const uint4 &c, int L, uint64_t th0, uint64_t th1) {
+  const uint64_t c0 = ((uint64_t)c.y << 32) | c.x, c1 = ((uint64_t)c.w << 32) | c.z;
+  const uint64_t m1 = L >= 8 ? ~0ull : (~0ull << (8 * (8 - L)));
+  const uint64_t m0 = L <= 8 ? 0ull : (L >= 16 ? ~0ull : (~0ull << (8 * (16 - L))));
+  return (((th0 ^ c0) & m0) | ((th1 ^ c1) & m1)) == 0;
+}
+
+__device__ __forceinline__ void load_tail16(const SeedArgs &a, int64_t p, uint64_t &th0, uint64_t &th1) {
+  th0 = th1 = 0;
+  if (p >= 15) {                                       // two unaligned 8-byte loads
+    __builtin_memcpy(&th0, a.text + p - 15, 8);
+    __builtin_memcpy(&th1, a.text + p - 7, 8);
+  } else {
+    for (int i = 0; i <= (int)p; ++i) {                // the very start of the stream
+      const uint64_t b = a.text[p - i];
+      if (i < 8) th1 |= b << (8 * (7 - i)); else th0 |= b << (8 * (15 - i));
     }
   }
-  // report once: only through the combo made of the first r clean pieces
-  uint64_t first = 0;
-  const uint64_t field = (1ull << (2 * a.pb)) - 1ull;
-  for (int j = 0, t = 0; j < m && t < a.r; ++j)
-    if (!(dirty >> j & 1)) { first |= field << (2 * a.pb * j); ++t; }
-  if (first != (((uint64_t)mhi << 32) | mlo)) return;
-  if (!partner_possible(a, p, pi, L)) return;                   // exact_halves -k: see partner_possible
+}
+
+// all loads dependent (rare paths, and pattern sets of mixed length)
+__device__ __forceinline__ bool half_seed_ok(const SeedArgs &a, int64_t p, uint32_t pi, uint32_t *pid) {
+  const uint4 *rec = reinterpret_cast<const uint4 *>(a.pat_codes + (size_t)pi * 32);
+  const uint4 c = rec[0], r = rec[1];
+  const int L = r.y & 0xffu, plen = (r.y >> 8) & 0xffu, side = (r.y >> 16) & 0xffu;
+  if (p + 1 - L < 0) return false;
+  uint64_t th0, th1;
+  load_tail16(a, p, th0, th1);
+  if (!half_codes_equal(c, L, th0, th1)) return false;
+  *pid = r.z;
+  const int64_t r0 = partner_window(p, L + plen, side, a.hk);
+  if (r0 < 0 || r0 + 24 > a.n) return true;            // near the stream ends: let the DP decide
+  uint64_t w0, w1, w2;
+  __builtin_memcpy(&w0, a.text + r0, 8);
+  __builtin_memcpy(&w1, a.text + r0 + 8, 8);
+  __builtin_memcpy(&w2, a.text + r0 + 16, 8);
+  return partner_possible(a, plen, r.x, w0, w1, w2);
+}
+
+__device__ __forceinline__ pm_hit half_seed_record(int64_t p, uint32_t pid) {
+  pm_hit hh;
+  hh.end = p + 1; hh.pid = pid; hh.k = 0;
+  hh.aux[0] = 3; hh.aux[1] = hh.aux[2] = 0;
+  return hh;
+}
+
+// out-of-line copy for the rare paths (second match in a bucket, probe continuation).  The main
+// path of the HALVES kernel inlines the test -- every seed gets there -- and writes its records into
+// slots it reserves 64 at a time: one atomic on the shared counter per record serialises the chip
+// (10^7 same-address atomics cost 25 ms).  Unused slots of a block are marked PM_SEED_HOLE.
+__device__ __noinline__ void verify_half(const SeedArgs *ap, int64_t p, uint32_t pi) {
+  const SeedArgs &a = *ap;
+  uint32_t pid = 0;
+  if (!half_seed_ok(a, p, pi, &pid)) return;
   const unsigned long long o = atomicAdd(a.counter, 1ull);
-  if (o < a.cap) {
-    pm_hit hh;
-    hh.end = p + 1; hh.pid = a.pat_id[pi]; hh.k = (uint8_t)ham;
-    hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
-    a.out[o] = hh;
-  }
+  if (o < a.cap) a.out[o] = half_seed_record(p, pid);
 }
 
 template <bool HALVES>
 __device__ __forceinline__ void verify_hit(const SeedArgs *ap, uint32_t mlo, uint32_t mhi, int64_t p, uint32_t pi) {
-  if (HALVES) verify_half(ap, mlo, mhi, p, pi); else verify_exact(ap, mlo, mhi, p, pi);
+  if (HALVES) verify_half(ap, p, pi); else verify_exact(ap, mlo, mhi, p, pi);
 }
 
 // packed distance (2 bits per base) never exceeds the true one: a cheap necessary condition
@@ -259,7 +309,7 @@ __device__ __forceinline__ bool packed_close(const uint2 &pp, uint64_t W, int k)
 
 template <bool HALVES>
 __device__ __forceinline__ void verify_pattern(const SeedArgs &a, uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p, uint32_t pi) {
-  if (packed_close(a.pat40[pi], W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pi);
+  if (HALVES || packed_close(a.pat40[pi], W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pi);
 }
 
 // slots of a loaded bucket whose fingerprint matches, as a bit mask; bit 8 = the bucket is full
@@ -387,19 +437,43 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   //   mostly idle one per Q1 batch.
   uint2 *queue2 = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_WORDS) + WAVES * QCAP + wave * SEED_Q2CAP;
   int q2n = 0;
+  // HALVES: records go to slots reserved SEED_OUT_BLOCK at a time (wave-uniform state)
+  unsigned long long ob_next = 0;
+  int ob_left = 0;
+  auto emit_half = [&](bool pass, int64_t p, uint32_t pid) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(pass);
+    if (bal == 0) return;
+    const int c = __popcll(bal);
+    if (c > ob_left) {
+      if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+      ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)base);
+      ob_left = SEED_OUT_BLOCK;
+    }
+    if (pass) {
+      const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+      if (slot < a.cap) a.out[slot] = half_seed_record(p, pid);
+    }
+    ob_next += c; ob_left -= c;
+  };
   auto process_q2 = [&]() __attribute__((always_inline)) {
+    if (a.debug & 2) { q2n = 0; return; }
     for (int base = 0; base < q2n; base += 64) {
       const bool on = base + lane < q2n;
       uint32_t wlo = 0, whi = 0, h2 = 0, mm = 0, pidx = 0;
       int64_t p = 0;
       uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
       uint2 pp = make_uint2(0, 0);
+      uint64_t th0 = 0, th1 = 0;
       if (on) {
         const uint2 e = queue2[base + lane];
         wlo = e.x & lo_mask; whi = e.y & 0xffu & hi_mask; p = ws + (e.y >> 8);
         h2 = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
         const size_t b = h2 >> a.bucket_shift;
         b0 = buckets[2 * b]; b1 = buckets[2 * b + 1];
+        if (HALVES) load_tail16(a, p, th0, th1);                   // independent of the bucket: same round trip
         mm = match_mask(b0, b1, h2 << a.idx_bits, imask);
       }
       const uint32_t sl[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -409,12 +483,38 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
         pidx = slot & imask;
-        pp = a.pat40[pidx];
+        if (!HALVES) pp = a.pat40[pidx];                             // halves: the record compare decides
       }
-      if (mm & 511u) {
+      if (HALVES) {                                                // wave-uniform: block-reserved output
+        uint32_t pid = 0;
+        bool pass = false;
+        if ((mm & 255u) && !(a.debug & 4)) {
+          if (a.hfast) {
+            // record and partner window in one round trip (side = parity of the half's index)
+            const uint4 *rec = reinterpret_cast<const uint4 *>(a.pat_codes + (size_t)pidx * 32);
+            const int64_t r0 = partner_window(p, a.hfast, pidx & 1, a.hk);
+            const bool inside = r0 >= 0 && r0 + 24 <= a.n;
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            const uint4 c = rec[0], r = rec[1];
+            if (inside) {
+              __builtin_memcpy(&w0, a.text + r0, 8);
+              __builtin_memcpy(&w1, a.text + r0 + 8, 8);
+              __builtin_memcpy(&w2, a.text + r0 + 16, 8);
+            }
+            const int L = r.y & 0xffu, plen = (r.y >> 8) & 0xffu;
+            pid = r.z;
+            pass = p + 1 - L >= 0 && half_codes_equal(c, L, th0, th1) &&
+                   (!inside || partner_possible(a, plen, r.x, w0, w1, w2));
+          } else {
+            pass = half_seed_ok(a, p, pidx, &pid);
+          }
+        }
+        emit_half(pass, p, pid);
+      }
+      if ((mm & 511u) && !(a.debug & 4)) {
         const uint64_t W = ((uint64_t)whi << 32) | wlo;
         if (mm & 255u) {
-          if (packed_close(pp, W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pidx);
+          if (!HALVES && packed_close(pp, W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pidx);
           uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);         // matches beyond the first (rare)
           while (rest) {
             const int sidx = __ffs(rest) - 1;
@@ -527,6 +627,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   drain();
   finish();
   process_q2();
+  if (HALVES && lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
 }
 
 }  // namespace
@@ -620,6 +721,13 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       for (size_t i = 0; i < ps.size(); ++i) { const int b2 = base2((unsigned char)ps[i]); if (b2 < 0) return "pattern with characters other than A,C,G,T"; w2 |= (uint32_t)b2 << (2 * i); }
       t.part32[j] = w2; t.part_len[j] = (uint8_t)ps.size(); t.part_side[j] = (*sides)[j];
     }
+  t.hfast = 0;
+  if (partners && np > 0) {                        // same total length everywhere and side = parity of the index?
+    const int tot = (int)pats[0].s.size() + t.part_len[0];
+    bool ok = true;
+    for (size_t j = 0; j < np && ok; ++j) ok = (int)pats[j].s.size() + t.part_len[j] == tot && t.part_side[j] == (j & 1);
+    if (ok) t.hfast = tot;
+  }
   // buckets of 8 slots, average fill <= 3; slot = fingerprint (high bits) | pattern index (low idx_bits)
   int idx_bits = 1;
   while (((size_t)1 << idx_bits) <= np) ++idx_bits;
@@ -648,6 +756,16 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
     t.pat_len[j] = (uint8_t)L;
     t.pat_id[j] = ids[j];
     for (int i = 0; i < L; ++i) t.pat_codes[j * 32 + i] = (uint8_t)alpha.nch[(unsigned char)s[i]];
+    if (partners) {                                // halves: the row doubles as the 32-byte record verify_half reads
+      if (L > 16) return "exact_halves half longer than 16 characters";
+      uint8_t *rec = &t.pat_codes[j * 32];
+      const uint32_t w32 = t.part32[j], idv = ids[j];
+      memmove(rec + 16 - L, rec, (size_t)L);         // codes right-aligned in bytes [16-L, 16)
+      memset(rec, 0, (size_t)(16 - L));
+      memcpy(rec + 16, &w32, 4);
+      rec[20] = (uint8_t)L; rec[21] = t.part_len[j]; rec[22] = t.part_side[j]; rec[23] = 0;
+      memcpy(rec + 24, &idv, 4);
+    }
     for (int ci = 0; ci < C; ++ci) {
       uint64_t cm = 0;
       for (int q = 0; q < t.r; ++q) cm |= pmask << (2 * t.pb * t.combos[ci][q]);
@@ -702,7 +820,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part32.data(), t.part32.size() * 4, (void **)&d->part32)) != hipSuccess) return e;
   if ((e = up(t.part_len.data(), t.part_len.size(), (void **)&d->part_len)) != hipSuccess) return e;
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
-  d->halves = t.halves; d->hk = t.hk;
+  d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast;
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
@@ -754,7 +872,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
   a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
-  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
+  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
