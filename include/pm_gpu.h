@@ -170,6 +170,11 @@ int pm_last_kernel_time(pm_handle *h, float *ms, int *launches);
 int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized, int32_t k, int32_t wildcards,
                       int32_t npat, const int32_t *patlen, const int32_t *esb, const int32_t *eeb);
 
+/* Measurement helper (no reference counterpart; SURVEY.md 8(d) "measured ceiling from the same
+ * box"): streams `bytes` of HBM at d_buf (16-byte aligned) through 16-byte loads `reps` times on
+ * `stream` and reports the read rate in GB/s. */
+int pm_measure_stream_read(const void *d_buf, size_t bytes, int reps, void *stream, float *gbytes_per_s);
+
 #ifdef __cplusplus
 }
 #endif

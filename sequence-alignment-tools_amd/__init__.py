@@ -12,5 +12,5 @@ or a gfx950 device is missing, calls fail loudly.
 from .pattern_match import (  # noqa: F401
     HIT_DTYPE, KERNEL_AUTO, KERNEL_BITPAR, KERNEL_SEED, SEM_AUTO, SEM_EXACT_BASES, SEM_EXACT_HALVES,
     SEM_FILTER_BITVEC, SEM_KEYWORD_TREE, SEM_SHIFT_AND, SEM_SHIFT_AND_INEXACT, PatternMatch, PmError,
-    build_library, library_path, load_library, pick_semantics, reverse_comp, sorted_tuples,
+    build_library, library_path, load_library, measure_stream_read, pick_semantics, reverse_comp, sorted_tuples,
 )

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
     "pm_finalize_device", "pm_align_hits",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
-    "pm_last_kernel_time", "pm_pick_semantics",
+    "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library():
         L.pm_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.pm_last_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.pm_pick_semantics.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pm_measure_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -96,6 +97,15 @@ def pick_semantics(alphabet_size, acgt_normalized, k, patterns, esb=None, eeb=No
     a = lambda x: None if x is None else np.ascontiguousarray(x, dtype=np.int32).ctypes.data_as(C.c_void_p)
     return L.pm_pick_semantics(alphabet_size, int(acgt_normalized), k, int(wildcards), len(patterns),
                                pl.ctypes.data_as(C.c_void_p), a(esb), a(eeb))
+
+
+def measure_stream_read(d_ptr, nbytes, reps=5, stream=0):
+    """Streaming-read rate (GB/s) of this box over an HBM buffer (pm_measure_stream_read)."""
+    g = C.c_float()
+    rc = load_library().pm_measure_stream_read(C.c_void_p(d_ptr), C.c_size_t(nbytes), int(reps), C.c_void_p(stream), C.byref(g))
+    if rc:
+        raise PmError(rc, "pm_measure_stream_read failed")
+    return g.value
 
 
 def reverse_comp(p):
