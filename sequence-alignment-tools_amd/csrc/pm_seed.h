@@ -34,6 +34,7 @@ struct SeedTables {
   std::vector<uint8_t> pat_codes;                 // 32 bytes per pattern
   bool halves = false; int hk = 0;                // exact_halves -k mode: partner half per pattern
   int hfast = 0;                                  // see SeedArgs::hfast
+  int eos_code = -1;
   std::vector<uint32_t> part32;
   std::vector<uint8_t> part_len, part_side;
   uint8_t cmap[256];
@@ -45,7 +46,7 @@ struct SeedDevice {
   void *pat40 = nullptr, *d_args = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr;
   uint32_t *part32 = nullptr;
-  bool halves = false; int hk = 0, hfast = 0;
+  bool halves = false; int hk = 0, hfast = 0, eos_code = -1;
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
   int mode = 0;
   int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;

@@ -64,6 +64,7 @@ struct SeedArgs {
   pm_hit *out;
   unsigned long long *counter;
   unsigned long long cap;
+  int eos_code;                         // stream code of the end-of-sequence character, -1 = none
   int halves, hk;                       // exact_halves -k: patterns are halves, partner prefilter for hk edits
   int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
                                         // partner's stream window is known before the half's record is read
@@ -204,21 +205,35 @@ __device__ __noinline__ void verify_exact(const SeedArgs *ap, uint32_t mlo, uint
   const int L = a.pat_len[pi];
   const int64_t start = p + 1 - L;
   if (start < 0) return;
-  const uint8_t *pc = a.pat_codes + (size_t)pi * 32;
-  int ham = 0;
-  uint32_t dirty = 0;                                 // pieces (of the last Lw bases) with a mismatch
-  bool left_clean = true, right_clean = true;
-  const int m = a.k + a.r;
-  for (int i = 0; i < L; ++i) {
-    const uint8_t tc = a.text[start + i];
-    if (a.cmap[tc] == 1) return;                      // EOS inside the window: never a candidate
-    if (tc != pc[i]) {
-      if (++ham > a.k) return;
-      if (i < L / 2) left_clean = false; else right_clean = false;
-      const int j = i - (L - a.Lw);                   // position inside the seeded suffix
-      if (j >= 0 && j / a.pb < m) dirty |= 1u << (j / a.pb);
-    }
+  // four stream bytes against four pattern codes per step, per-byte verdicts by SWAR.  Rolled on
+  // purpose: this function must stay small in registers, or the callers' allocation suffers.
+  const uint32_t *pc = reinterpret_cast<const uint32_t *>(a.pat_codes + (size_t)pi * 32);
+  const uint32_t eb = (uint32_t)(a.eos_code & 0xff) * 0x01010101u;
+  uint32_t mism = 0, eos = 0;                         // bit i: stream byte i differs from the pattern / is EOS
+#pragma unroll 1
+  for (int d = 0; 4 * d < L; ++d) {
+    const int64_t off = start + 4 * d;
+    uint32_t tw = 0;
+    if (off + 4 <= a.n) __builtin_memcpy(&tw, a.text + off, 4);
+    else
+      for (int b = 0; off + b < a.n; ++b) tw |= (uint32_t)a.text[off + b] << (8 * b);   // last bytes of the stream
+    const uint32_t x = tw ^ pc[d], z = tw ^ eb;
+    const uint32_t y = (x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    const uint32_t e = ~(z | ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    mism |= (((y >> 7) & 1u) | ((y >> 14) & 2u) | ((y >> 21) & 4u) | ((y >> 28) & 8u)) << (4 * d);
+    eos |= (((e >> 7) & 1u) | ((e >> 14) & 2u) | ((e >> 21) & 4u) | ((e >> 28) & 8u)) << (4 * d);
   }
+  const uint32_t lenmask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+  mism &= lenmask;
+  if (a.eos_code >= 0 && (eos & lenmask)) return;     // EOS inside the window: never a candidate
+  const int ham = __popc(mism);                       // N (or any other code) = mismatch
+  if (ham > a.k) return;
+  const int half = L / 2, m = a.k + a.r;
+  const bool left_clean = (mism & ((1u << half) - 1u)) == 0, right_clean = (mism >> half) == 0;
+  uint32_t dirty = 0;                                 // pieces (of the last Lw bases) with a mismatch
+  const uint32_t sm = mism >> (L - a.Lw), pmask = (1u << a.pb) - 1u;
+  for (int j = 0; j < m; ++j)
+    if ((sm >> (j * a.pb)) & pmask) dirty |= 1u << j;
   // report once: only through the combo made of the first r clean pieces
   uint64_t first = 0;
   const uint64_t field = (1ull << (2 * a.pb)) - 1ull;
@@ -745,7 +760,8 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.bitmap2.assign((size_t)C << (lb2 - 5), 0);
   t.slots.assign((size_t)C * nslots, EMPTY);
   for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
-  if (eos_code >= 0 && eos_code < 256) t.cmap[eos_code] = 1;
+  t.eos_code = -1;
+  if (eos_code >= 0 && eos_code < 256) { t.cmap[eos_code] = 1; t.eos_code = eos_code; }
   const uint64_t pmask = (1ull << (2 * t.pb)) - 1ull;
   for (size_t j = 0; j < np; ++j) {
     const std::string &s = pats[j].s;
@@ -820,7 +836,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part32.data(), t.part32.size() * 4, (void **)&d->part32)) != hipSuccess) return e;
   if ((e = up(t.part_len.data(), t.part_len.size(), (void **)&d->part_len)) != hipSuccess) return e;
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
-  d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast;
+  d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code;
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
@@ -872,7 +888,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
   a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
-  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
+  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code; a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
