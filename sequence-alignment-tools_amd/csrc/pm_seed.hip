@@ -38,7 +38,7 @@ namespace {
 constexpr int QCAP = SEED_QCAP;           // queue entries per wave (8 B each)
 constexpr int WAVES = SEED_THREADS / 64;
 constexpr uint32_t EMPTY = 0xffffffffu;
-constexpr uint32_t HASH_LO = 0x9E3779B1u, HASH_HI = 0x9E3779u, HASH_SLOT = 0x85EBCA6Bu;
+constexpr uint32_t HASH_LO = 0x9E3779B1u, HASH_HI = 0x9E3779u, HASH_SLOT = 0x85EBCA6Bu, HASH_SEL = 0xC2B2AFu;
 
 struct SeedArgs;
 struct SeedArgs {
@@ -112,19 +112,23 @@ __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_
 
 // Hash of the combo's part of a window.  MODE 0: any piece layout (mask + fold + multiply);
 // MODE 1: 4-base pieces = bytes, three of them gathered by one v_perm, 24-bit multiply;
-// MODE 2: four byte pieces, 32-bit multiply.  The Bloom word comes from the low 15 bits, the
-// three bit selectors from bits 27.., 22.., 17.. (seed_build mirrors this on the host).
+// MODE 2: four byte pieces, 32-bit multiply.  The Bloom word index is the top 15 bits; *selsrc is
+// what bloom_selectors derives the three bit selectors from (seed_build mirrors both on the host).
 template <int MODE>
-__device__ __host__ __forceinline__ uint32_t window_hash(uint32_t wlo, uint32_t whi, uint32_t mlo, uint32_t mhi, uint32_t sel) {
+__device__ __host__ __forceinline__ uint32_t window_hash(uint32_t wlo, uint32_t whi, uint32_t mlo, uint32_t mhi, uint32_t sel, uint32_t *selsrc = nullptr) {
   if (MODE == 0) {
     uint32_t x = (wlo & mlo) + (whi & mhi) * HASH_HI;
     x ^= x >> 16;
-    return x * HASH_LO;
+    x *= HASH_LO;
+    if (selsrc) *selsrc = x >> 8;
+    return x;
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t key = __builtin_amdgcn_perm(whi, wlo, sel);
-  if (MODE == 1) return __umul24(key, HASH_HI);
-  return key * HASH_LO;
+  if (MODE == 1) { if (selsrc) *selsrc = key; return __umul24(key, HASH_HI); }
+  const uint32_t h = key * HASH_LO;
+  if (selsrc) *selsrc = h >> 8;
+  return h;
 #else
   uint32_t key = 0;
   const uint64_t W = ((uint64_t)whi << 32) | wlo;
@@ -132,14 +136,31 @@ __device__ __host__ __forceinline__ uint32_t window_hash(uint32_t wlo, uint32_t 
     const uint32_t sb = (sel >> (8 * q)) & 0xffu;
     if (sb < 8) key |= (uint32_t)((W >> (8 * sb)) & 0xffu) << (8 * q);
   }
-  if (MODE == 1) return (uint32_t)((uint64_t)(key & 0xffffffu) * HASH_HI);
-  return key * HASH_LO;
+  if (MODE == 1) { if (selsrc) *selsrc = key; return (uint32_t)((uint64_t)(key & 0xffffffu) * HASH_HI); }
+  const uint32_t h = key * HASH_LO;
+  if (selsrc) *selsrc = h >> 8;
+  return h;
 #endif
 }
 
-// 1 if all three selected bits of the Bloom word are set (shift amounts use their low 5 bits)
-__device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h) {
-  return (word >> ((h >> 27) & 31)) & (word >> ((h >> 22) & 31)) & (word >> ((h >> 17) & 31)) & 1u;
+// The three bit selectors of a key are the low five bits of bytes 1, 2, 3 of a second 24-bit
+// product: each test is then one SDWA shift (the byte is picked by the operand selector, the
+// shifter only looks at five bits).  seed_build mirrors bloom_selectors on the host.
+__device__ __host__ __forceinline__ uint32_t bloom_selectors(uint32_t selsrc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(selsrc, HASH_SEL);
+#else
+  return (uint32_t)((uint64_t)(selsrc & 0xffffffu) * HASH_SEL);
+#endif
+}
+
+// bit 0 = 1 iff all three selected bits of the Bloom word are set
+__device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t hsel) {
+  uint32_t a, b, c;
+  asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(hsel), "v"(word));
+  asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(b) : "v"(hsel), "v"(word));
+  asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(c) : "v"(hsel), "v"(word));
+  return a & b & c;
 }
 
 // exact_halves with edits (-k): the "patterns" are halves and a seed is an exact occurrence of one
@@ -611,8 +632,10 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     for (int i = 0; i < 16; ++i) {
       uint32_t wlo, whi;
       window(i, prev2, prev1, cur, wlo, whi);
-      hs[i] = window_hash<MODE>(wlo, whi, mlo, mhi, sel);
-      wd[i] = bloom[hs[i] & (SEED_BLOOM_WORDS - 1)];
+      uint32_t ss;
+      const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
+      hs[i] = bloom_selectors(ss);
+      wd[i] = bloom[h >> 17];                                      // word index = the 15 best-mixed bits
     }
     // part 2: three bit tests per window; the verdicts are funnelled into one register
     uint32_t acc = 0;
@@ -786,11 +809,14 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       uint64_t cm = 0;
       for (int q = 0; q < t.r; ++q) cm |= pmask << (2 * t.pb * t.combos[ci][q]);
       const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32), mlo = (uint32_t)cm, mhi = (uint32_t)(cm >> 32);
-      const uint32_t h = t.mode == 0 ? window_hash<0>(wlo, whi, mlo, mhi, 0)
-                       : t.mode == 1 ? window_hash<1>(wlo, whi, mlo, mhi, t.perm_sel[ci])
-                                     : window_hash<2>(wlo, whi, mlo, mhi, t.perm_sel[ci]);
-      t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h & (SEED_BLOOM_WORDS - 1))] |=
-          (1u << ((h >> 27) & 31)) | (1u << ((h >> 22) & 31)) | (1u << ((h >> 17) & 31));
+      uint32_t ss = 0;
+      const uint32_t h = t.mode == 0 ? window_hash<0>(wlo, whi, mlo, mhi, 0, &ss)
+                       : t.mode == 1 ? window_hash<1>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss)
+                                     : window_hash<2>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss);
+      const uint32_t hsel = bloom_selectors(ss);
+      static_assert(SEED_BLOOM_WORDS == 1 << 15, "word index = h >> 17");
+      t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h >> 17)] |=
+          (1u << ((hsel >> 8) & 31)) | (1u << ((hsel >> 16) & 31)) | (1u << ((hsel >> 24) & 31));
       const uint32_t h2 = h * HASH_SLOT;
       t.bitmap2[((size_t)ci << (lb2 - 5)) + (h2 >> (37 - lb2))] |= 1u << ((h2 >> (32 - lb2)) & 31);
       const uint32_t imask = (1u << idx_bits) - 1u;
