@@ -151,6 +151,12 @@ int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scan
 typedef struct { int64_t start, end; int32_t editdist, value; } pm_alignment;
 int pm_align_hits(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out);
 
+/* Same, plus what the caller's formatter prints per hit (primer_match.cc:1196-1202): the alignment
+ * string pa->alignment_string() ('|' equal, '*' substitution, '^' insertion, 'v' deletion, '!'
+ * constraint violation; pattern_alignment.h:122-165) and the matching text pa->matching_text(),
+ * both NUL-terminated at ops + i*stride and text + i*stride.  stride > longest pattern + k. */
+int pm_align_hits_text(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride);
+
 /* PatternMatch::reset (pattern_match.h:134): forget scan state, keep patterns and text. */
 int pm_reset(pm_handle *h);
 void pm_destroy(pm_handle *h);

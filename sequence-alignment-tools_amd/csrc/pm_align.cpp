@@ -29,7 +29,7 @@ Band make_band(AlignScratch &scr, int rows, int W, int b) {
 // window chars.  Row 0 is free while t <= delta (:276-279); costs 0/1/1/1, violation 5k+1 (:131).
 AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, int64_t end2,
                            const char *pat, int L, int lconst, int rconst,
-                           const AlignParams &prm, AlignScratch &scr) {
+                           const AlignParams &prm, AlignScratch &scr, std::string *ops) {
   AlignResult r;
   r.end = end; r.editdist = INT32_MAX;
   const int k = prm.k, viol = 5 * k + 1, b = prm.indels ? k : 0;
@@ -106,6 +106,8 @@ AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, i
     else if (ins) { --t; last = S_INS; ++nins; }
     else if (ac & VIOL) { p = 0; t = 0; last = S_VIOL; ++nviol; }
     else return r;
+    // pattern_alignment::alignment_string's characters (pattern_alignment.h:122-165), pattern start first
+    if (ops) ops->push_back(last == S_EQ ? '|' : last == S_SUB ? '*' : last == S_INS ? '^' : last == S_DEL ? 'v' : '!');
   }
   r.start = end2 - best;                                  // :603-610
   r.end = end2 - t;

@@ -7,6 +7,7 @@
 // reference is honoured; parity is checked against oracle/ and tests/golden by the tests.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace pm {
@@ -35,7 +36,7 @@ struct AlignScratch {
 // range [win_start, end2); the caller guarantees win_start == max(0, end - L - k).
 AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, int64_t end2,
                            const char *pat, int L, int lconst, int rconst,
-                           const AlignParams &prm, AlignScratch &scr);
+                           const AlignParams &prm, AlignScratch &scr, std::string *ops = nullptr);
 
 // Seed extension, yes/no form.  lmatch: left part (len1 chars) matched exactly ending at end1,
 // `win` = chars of [end1, end1 + len2 + k).  rmatch: right part (len2 chars) matched exactly

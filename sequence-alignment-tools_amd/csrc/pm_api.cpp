@@ -942,8 +942,20 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
 // (pattern_alignment.cc:29-43) for k == 0, else editdist_alignment(key, key, k, eos, wc, tn,
 // indels, dm, esb, eeb, yesno=false) with its traceback; editdist == INT32_MAX is the CLI's
 // "Bogus hit" (constraint violation).
+static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride);
+
 extern "C" int pm_align_hits(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out) {
+  return align_hits_impl(h, hits, n, out, nullptr, nullptr, 0);
+}
+
+extern "C" int pm_align_hits_text(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride) {
+  if (!ops || !text || stride == 0) return fail(h, PM_E_INVALID, "pm_align_hits_text: bad arguments");
+  return align_hits_impl(h, hits, n, out, ops, text, stride);
+}
+
+static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride) {
   if (!h || !h->inited || (!hits && n) || (!out && n)) return fail(h, PM_E_INVALID, "pm_align_hits: bad arguments");
+  if (ops && h->cfg.wildcards) return fail(h, PM_E_UNSUPPORTED, "pm_align_hits_text: wildcard alignments (exact_wc_alignment) are not built");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int k = h->cfg.k;
   std::vector<Window> wins(n);
@@ -961,10 +973,26 @@ extern "C" int pm_align_hits(pm_handle *h, const pm_hit *hits, size_t n, pm_alig
   AlignParams prm; prm.k = k; prm.indels = h->cfg.indels != 0; prm.eos = (uint8_t)h->cfg.eos;
   for (size_t i = 0; i < n; ++i) {
     const int L = (int)pp[i]->s.size();
-    if (k == 0) { out[i].start = hits[i].end - L; out[i].end = hits[i].end; out[i].editdist = 0; out[i].value = 0; continue; }
+    if (k == 0) {                                                    // exact_alignment (pattern_alignment.cc:29-43)
+      out[i].start = hits[i].end - L; out[i].end = hits[i].end; out[i].editdist = 0; out[i].value = 0;
+      if (ops) {
+        if ((size_t)L + 1 > stride) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
+        memset(ops + i * stride, '|', (size_t)L); ops[i * stride + L] = 0;
+        memcpy(text + i * stride, pp[i]->s.data(), (size_t)L); text[i * stride + L] = 0;
+      }
+      continue;
+    }
+    std::string opstr;
     AlignResult r = editdist_align(h->winbuf.data() + wins[i].off, wins[i].start, hits[i].end, hits[i].end,
-                                   pp[i]->s.data(), L, pp[i]->esb, pp[i]->eeb, prm, h->scratch);
+                                   pp[i]->s.data(), L, pp[i]->esb, pp[i]->eeb, prm, h->scratch, ops ? &opstr : nullptr);
     out[i].start = r.start; out[i].end = r.end; out[i].editdist = r.editdist; out[i].value = r.value;
+    if (ops) {
+      const int64_t tl = r.end - r.start;                              // matching text (pattern_alignment.cc:603-606)
+      if (opstr.size() + 1 > stride || tl < 0 || (size_t)tl + 1 > stride) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
+      memcpy(ops + i * stride, opstr.data(), opstr.size()); ops[i * stride + opstr.size()] = 0;
+      for (int64_t q = 0; q < tl; ++q) text[i * stride + q] = (char)h->winbuf[wins[i].off + (r.start - wins[i].start) + q];
+      text[i * stride + tl] = 0;
+    }
   }
   return PM_OK;
 }

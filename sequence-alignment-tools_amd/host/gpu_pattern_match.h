@@ -74,6 +74,7 @@ class GpuPatternMatch {
   int selected_semantics() const;
   int selected_kernel() const;
   void chunk_bytes(int64_t c) { chunk_ = c; }
+  pm_handle *handle() const { return h_; }     // for the caller's per-hit re-alignment (pm_align_hits_text)
  private:
   [[noreturn]] void fatal(const char *what) const;
   pm_handle *h_ = nullptr;

@@ -20,7 +20,7 @@ PM_E_OVERFLOW = -5
 ABI_SYMBOLS = [
     "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_candidates",
     "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
-    "pm_finalize_device", "pm_align_hits",
+    "pm_finalize_device", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
 ]
@@ -79,6 +79,7 @@ def load_library():
         L.pm_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_finalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_align_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pm_align_hits_text.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.pm_reset.argtypes = [C.c_void_p]
         L.pm_selected_semantics.argtypes = [C.c_void_p]
         L.pm_selected_kernel.argtypes = [C.c_void_p]
