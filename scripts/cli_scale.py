@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the command lines at BASELINE.json's sizes (run on the GPU box).
+
+Writes a synthetic database directly in compress_seq's file formats (<db>.sqn/.tbl/.idb/.hdr:
+uniform A,C,G,T, 24 entries), a primer list (10 % planted with 0-2 substitutions) and a UniSTS
+primer-pair file (10 % planted at amplicon length U[100,1000]), then times
+    pm_primer_match -K 2 -r -c          (configs[2]/[3] through the CLI)
+    pm_primer_match -k 1 -r -A ...      (alignment output)
+    pm_pcr_match    -k 1 -S ... -M 1000 (configs[4])
+with -v phase timings, and -- on a bounded sample of the same inputs -- the reference binaries
+oracle/_ref/primer_match and oracle/_ref/pcr_match (1 thread) when they are present.
+Prints one JSON object.  Usage: python scripts/cli_scale.py --bases 3000000000 --primers 100000 --pairs 100000
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "sequence-alignment-tools_amd", "host")
+REF = os.path.join(ROOT, "oracle", "_ref")
+COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def revcomp(b):
+    return b.translate(COMP)[::-1]
+
+
+def write_db(prefix, codes, entries):
+    """codes: uint8 array of bases (0..3), split into `entries` equal entries."""
+    n = codes.size
+    per = n // entries
+    bounds = [i * per for i in range(entries)] + [n]
+    with open(prefix + ".sqn", "wb") as f:
+        f.write(b"\x04")
+        for i in range(entries):
+            f.write(codes[bounds[i]:bounds[i + 1]].tobytes())
+            f.write(b"\x04")
+    with open(prefix + ".tbl", "wb") as f:
+        f.write(b"ACGT\n")
+    hdr = b""
+    keys, vals = [], []
+    pos = 1
+    for i in range(entries):
+        keys.append(pos)
+        vals.append(len(hdr))
+        hdr += ("entry%d synthetic uniform DNA\n" % (i + 1)).encode()
+        pos += bounds[i + 1] - bounds[i] + 1
+    keys.append(pos + 1)                       # compress_seq counts the final EOS twice
+    vals.append(len(hdr))
+    with open(prefix + ".hdr", "wb") as f:
+        f.write(hdr)
+    with open(prefix + ".idb", "wb") as f:
+        f.write(struct.pack("<Q", len(keys)))
+        for k, v in zip(keys, vals):
+            f.write(struct.pack("<qq", k, v))
+    return bounds
+
+
+def mutate(rng, w, nsub):
+    w = bytearray(w)
+    for _ in range(nsub):
+        i = int(rng.integers(0, len(w)))
+        w[i] = rng.choice([c for c in b"ACGT" if c != w[i]])
+    return bytes(w)
+
+
+def run_timed(cmd, stdout):
+    t0 = time.time()
+    with open(stdout, "wb") as f:
+        r = subprocess.run(cmd, stdout=f, stderr=subprocess.PIPE)
+    dt = time.time() - t0
+    return dt, r.returncode, r.stderr.decode("latin1")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bases", type=int, default=1_000_000_000)
+    ap.add_argument("--entries", type=int, default=24)
+    ap.add_argument("--primers", type=int, default=100_000)
+    ap.add_argument("--pairs", type=int, default=100_000)
+    ap.add_argument("--ref-sample", type=int, default=30_000_000, help="bases for the reference binaries (0 = skip)")
+    ap.add_argument("--tmp", default=None)
+    args = ap.parse_args()
+    rng = np.random.default_rng(20260101)
+    res = {"bases": args.bases, "entries": args.entries, "primers": args.primers, "pairs": args.pairs, "runs": {}}
+    with tempfile.TemporaryDirectory(dir=args.tmp) as d:
+        t0 = time.time()
+        codes = rng.integers(0, 4, size=args.bases, dtype=np.uint8)
+        db = os.path.join(d, "db")
+        bounds = write_db(db, codes, args.entries)
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        head = lut[codes[:min(args.bases, 1 << 26)]].tobytes()           # planted sites come from the first 64 Mbp
+        # primers
+        prim = []
+        for i in range(args.primers):
+            if i % 10 == 0:
+                a = int(rng.integers(0, len(head) - 20))
+                prim.append(mutate(rng, head[a:a + 20], i // 10 % 3))
+            else:
+                prim.append(lut[rng.integers(0, 4, size=20)].tobytes())
+        with open(os.path.join(d, "primers.txt"), "wb") as f:
+            f.write(b"\n".join(prim) + b"\n")
+        # primer pairs (UniSTS lines)
+        per = args.bases // args.entries
+        with open(os.path.join(d, "pairs.sts"), "wb") as f:
+            for i in range(args.pairs):
+                if i % 10 == 0:
+                    amp = int(rng.integers(100, 1001))
+                    a = int(rng.integers(0, min(len(head), per) - amp))       # inside the first entry
+                    fwd, rev = head[a:a + 20], revcomp(head[a + amp - 20:a + amp])
+                    if i % 20 == 0:
+                        fwd = mutate(rng, fwd, 1)
+                else:
+                    amp = 500
+                    fwd, rev = lut[rng.integers(0, 4, size=20)].tobytes(), lut[rng.integers(0, 4, size=20)].tobytes()
+                f.write(b"STS%d\t%s\t%s\t%d\tACC%d\t1\tALT%d\tsynthetic\n" % (i + 1, fwd, rev, amp, i + 1, i + 1))
+        res["generate_s"] = time.time() - t0
+        del codes
+
+        runs = [
+            ("primer_match_K2_counts", [os.path.join(HOST, "pm_primer_match"), "-i", db, "-P", os.path.join(d, "primers.txt"), "-K", "2", "-r", "-c", "-v"]),
+            ("primer_match_k1_align", [os.path.join(HOST, "pm_primer_match"), "-i", db, "-P", os.path.join(d, "primers.txt"), "-k", "1", "-r", "-A", "%i %r %s %e %d %H\\n", "-v"]),
+            ("pcr_match_k1_sts", [os.path.join(HOST, "pm_pcr_match"), "-i", db, "-S", os.path.join(d, "pairs.sts"), "-k", "1", "-M", "1000", "-A", "%I %H %>s %<e %l %>d %<d %r\\n", "-v"]),
+        ]
+        for name, cmd in runs:
+            dt, rc, err = run_timed(cmd, os.path.join(d, name + ".out"))
+            with open(os.path.join(d, name + ".out"), "rb") as f:
+                nlines = sum(1 for _ in f)
+            res["runs"][name] = {"wall_s": dt, "rc": rc, "output_lines": nlines, "gbases_per_s_wall": args.bases / dt / 1e9,
+                                 "phases": [l for l in err.splitlines() if l.startswith("[") or l.startswith("scan")]}
+            print(name, "%.2f s" % dt, file=sys.stderr, flush=True)
+
+        # the reference binaries on a bounded sample of the same database (same primer files)
+        if args.ref_sample > 0 and os.path.exists(os.path.join(REF, "pcr_match")):
+            ns = min(args.ref_sample, args.bases)
+            codes = np.fromfile(db + ".sqn", dtype=np.uint8, count=ns + 1)[1:]
+            sdb = os.path.join(d, "sample")
+            write_db(sdb, codes, 1)
+            for name, cmd in [
+                ("ref_primer_match_k1_align", [os.path.join(REF, "primer_match"), "-i", sdb, "-P", os.path.join(d, "primers.txt"), "-k", "1", "-r", "-A", "%i %r %s %e %d %H\\n"]),
+                ("ref_pcr_match_k1_sts", [os.path.join(REF, "pcr_match"), "-i", sdb, "-S", os.path.join(d, "pairs.sts"), "-k", "1", "-M", "1000", "-A", "%I %H %>s %<e %l %>d %<d %r\\n"]),
+            ]:
+                dt, rc, err = run_timed(cmd, os.path.join(d, name + ".out"))
+                with open(os.path.join(d, name + ".out"), "rb") as f:
+                    nlines = sum(1 for _ in f)
+                res["runs"][name] = {"wall_s": dt, "rc": rc, "output_lines": nlines, "sample_bases": ns, "gbases_per_s_wall": ns / dt / 1e9,
+                                     "stderr_tail": err[-300:]}
+                print(name, "%.2f s" % dt, file=sys.stderr, flush=True)
+            # same sample through our CLIs: outputs must agree
+            for name, exe, ref in [("primer_match_k1_align", "pm_primer_match", "ref_primer_match_k1_align"), ("pcr_match_k1_sts", "pm_pcr_match", "ref_pcr_match_k1_sts")]:
+                cmd = [c if c != db else sdb for c in dict(runs)[name]]
+                dt, rc, err = run_timed(cmd, os.path.join(d, name + ".sample.out"))
+                with open(os.path.join(d, name + ".sample.out"), "rb") as f:
+                    got = sorted(f.read().splitlines())
+                with open(os.path.join(d, ref + ".out"), "rb") as f:
+                    want = sorted(f.read().splitlines())
+                res["runs"][ref]["gpu_cli_same_output"] = got == want
+                res["runs"][ref]["gpu_cli_wall_s_on_sample"] = dt
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

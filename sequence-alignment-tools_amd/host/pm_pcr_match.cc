@@ -11,6 +11,8 @@
 // Not built (refused with a message): wildcard alignments with k > 0, raw FASTA / .sqz databases.
 #include <unistd.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +55,19 @@ struct Options {
           "  -A <format>  -R <int>  -N <int>  -D (0|2|3)  -B  -v  -h\n");
   exit(1);
 }
+
+// -v: wall-clock seconds per phase on stderr (the reference prints timestamp() lines there)
+struct Phases {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[%8.3f s, +%7.3f] %s\n", std::chrono::duration<double>(now - t0).count(),
+            std::chrono::duration<double>(now - last).count(), what);
+    last = now;
+  }
+};
 
 int tilde(const char *a) { return a[0] == '~' ? -atoi(a + 1) : atoi(a); }
 
@@ -232,6 +247,7 @@ struct Hit { int64_t key; unsigned long id; unsigned char value; };
 
 int main(int argc, char **argv) {
   Options opt = parse(argc, argv);
+  Phases ph; ph.on = opt.verbose;
   std::ofstream fout;
   if (!opt.outfile.empty()) fout.open(opt.outfile.c_str(), std::ios::out | std::ios::app | std::ios::ate);
   std::ostream &out = opt.outfile.empty() ? std::cout : fout;
@@ -316,7 +332,9 @@ int main(int argc, char **argv) {
   }
 
   // ---- database and engine (pcr_match.cc:911-931) -------------------------------------------
+  ph.mark("Read primer pairs");
   SeqDb db(opt.database, opt.dbind, /*load_headers=*/true, /*check=*/true, /*upper_case=*/false, opt.eos_char);
+  ph.mark("Loaded sequence database");
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
   if (opt.node == 16) kernel = PM_KERNEL_BITPAR;
   else if (opt.node != 17 && opt.node != 0) semantics = opt.node;
@@ -328,6 +346,9 @@ int main(int argc, char **argv) {
   }
   BufferChars &ff = db.chars();
   pm.init(ff);
+  ph.mark("Primer index built, stream resident on the GPU");
+  double t_scan = 0, t_pair = 0;
+  unsigned long nhits = 0, npairs = 0;
 
   // ---- scan + pairing (pcr_match.cc:937-1259) ------------------------------------------------
   const size_t stride = maxlen + (size_t)opt.nmismatch + 2;
@@ -335,8 +356,13 @@ int main(int argc, char **argv) {
   pattern_hit_vector l;
   StsEntry null_sts;
   for (;;) {
+    const auto ts0 = std::chrono::steady_clock::now();
+    const size_t before = l.size();
     const bool more = pm.find_patterns(ff, l, opt.report_interval);
+    const auto ts1 = std::chrono::steady_clock::now();
+    t_scan += std::chrono::duration<double>(ts1 - ts0).count();
     if (!more && l.empty()) break;
+    nhits += l.size() - before;
     const int64_t oldcharspos = ff.pos();
     std::sort(l.begin(), l.end(), [](const pattern_hit &a, const pattern_hit &b) { return a.key != b.key ? a.key < b.key : a.id < b.id; });
     // per pattern id: hit indices in position order
@@ -452,6 +478,7 @@ int main(int argc, char **argv) {
       x.i = pind; x.sts = &stsref; x.ppo = ind < ind1;
       x.h = h.header; x.H = h.short_header; x.f = h.index;
       alignformat(out, opt.alignformat, x);
+      ++npairs;
     }
 
     // keep only the hits whose window is not complete yet (:1222-1252)
@@ -460,7 +487,10 @@ int main(int argc, char **argv) {
       if (live[j] != 0) keep.push_back(l[j]);
     l.swap(keep);
     ff.pos(oldcharspos);
+    t_pair += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count();
   }
+  if (opt.verbose) fprintf(stderr, "scan (find_patterns) %.3f s, pairing + re-align + report %.3f s, %lu primer hits, %lu amplicons\n", t_scan, t_pair, nhits, npairs);
+  ph.mark("Scanned sequence database");
   out.flush();
   return 0;
 }

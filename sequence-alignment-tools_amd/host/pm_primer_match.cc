@@ -12,6 +12,8 @@
 // the PRIMER3TM escapes %m %G and the peptide-mass escape %M.
 #include <unistd.h>
 
+#include <chrono>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +63,19 @@ struct Options {
           "  -D (0|2|3)  -I  -B  -v  -h\n");
   exit(1);
 }
+
+// -v: wall-clock seconds per phase on stderr (the reference prints timestamp() lines there)
+struct Phases {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[%8.3f s, +%7.3f] %s\n", std::chrono::duration<double>(now - t0).count(),
+            std::chrono::duration<double>(now - last).count(), what);
+    last = now;
+  }
+};
 
 int tilde(const char *a) { return a[0] == '~' ? -atoi(a + 1) : atoi(a); }
 
@@ -268,6 +283,7 @@ std::string with_gaps(const std::string &src, const std::string &ops, char gap_o
 
 int main(int argc, char **argv) {
   Options opt = parse(argc, argv);
+  Phases ph; ph.on = opt.verbose;
   std::ofstream fout;
   if (!opt.outfile.empty()) fout.open(opt.outfile.c_str(), std::ios::out | std::ios::app | std::ios::ate);
   std::ostream &out = opt.outfile.empty() ? std::cout : fout;
@@ -309,6 +325,7 @@ int main(int argc, char **argv) {
     }
   }
   if (patterns.empty()) return 0;
+  ph.mark("Read primers");
   if (opt.ucdict) for (std::string &p : patterns) uppercase(p);
 
   const unsigned long n = patterns.size();
@@ -352,6 +369,7 @@ int main(int argc, char **argv) {
 
   // ---- database and engine (primer_match.cc:1086-1112) --------------------------------------
   SeqDb db(opt.database, opt.dbind, opt.alignments && opt.dbindex, opt.dbindex, opt.ucdict, opt.eos_char);
+  ph.mark("Loaded sequence database");
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
   if (opt.node == 16) kernel = PM_KERNEL_BITPAR;
   else if (opt.node == 17 || opt.node == 0) kernel = PM_KERNEL_AUTO;
@@ -364,6 +382,9 @@ int main(int argc, char **argv) {
   }
   BufferChars &ff = db.chars();
   kt.init(ff);
+  ph.mark("Primer index built, stream resident on the GPU");
+  double t_scan = 0, t_report = 0;
+  unsigned long nhits = 0;
 
   // ---- scan loop (primer_match.cc:1114-1268) ------------------------------------------------
   const size_t stride = maxlen + (size_t)opt.nmismatch + 2;
@@ -372,7 +393,13 @@ int main(int argc, char **argv) {
   std::vector<pm_alignment> al;
   std::vector<char> opsbuf, textbuf;
   StsEntry null_sts;
-  while (kt.find_patterns(ff, l, opt.report_interval) || !l.empty()) {
+  for (;;) {
+    const auto ts0 = std::chrono::steady_clock::now();
+    const bool more = kt.find_patterns(ff, l, opt.report_interval);
+    const auto ts1 = std::chrono::steady_clock::now();
+    t_scan += std::chrono::duration<double>(ts1 - ts0).count();
+    if (!more && l.empty()) break;
+    nhits += l.size();
     const int64_t oldcharspos = ff.pos();
     hv.resize(l.size()); al.resize(l.size());
     opsbuf.assign(l.size() * stride, 0); textbuf.assign(l.size() * stride, 0);
@@ -422,7 +449,10 @@ int main(int argc, char **argv) {
     }
     l.clear();
     ff.pos(oldcharspos);
+    t_report += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count();
   }
+  if (opt.verbose) fprintf(stderr, "scan (find_patterns) %.3f s, re-align + report %.3f s, %lu hits\n", t_scan, t_report, nhits);
+  ph.mark("Scanned sequence database");
 
   // ---- counts (primer_match.cc:1270-1328) ---------------------------------------------------
   if (opt.counts) {
