@@ -17,6 +17,7 @@
 #include <unordered_map>
 
 #include "pm_internal.h"
+#include "pm_iupac.h"
 #include "pm_seed.h"
 
 using namespace pm;
@@ -24,11 +25,11 @@ using namespace pm;
 namespace pm {
 void Alphabet::set_raw() {
   size = 256;
-  for (int i = 0; i < 256; ++i) { ch[i] = (uint8_t)i; nch[i] = i; }
+  for (int i = 0; i < 256; ++i) { ch[i] = (uint8_t)i; nch[i] = i; present[i] = true; }
 }
 void Alphabet::set_table(const uint8_t *table, int len) {      // char_io.t:222-236
   size = len;
-  for (int i = 0; i < 256; ++i) { ch[i] = 0; nch[i] = -1; }
+  for (int i = 0; i < 256; ++i) { ch[i] = 0; nch[i] = -1; present[i] = true; }
   for (int i = 0; i < len; ++i) { ch[i] = table[i]; nch[table[i]] = i; }
 }
 }  // namespace pm
@@ -280,6 +281,9 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     if (table_len <= 0 || table_len > 256) return fail(h, PM_E_INVALID, "bad alphabet table length");
     h->alpha.set_table(table, table_len);
   } else h->alpha.set_raw();
+  // -w/-W on a raw stream: IUPAC classes name up to 16 letters each, the kernels keep 6 character
+  // classes in registers -- only the letters that occur in the stream need one
+  if (!table && h->cfg.wildcards) HIP_TRY(h, stream_presence(h->d_text, h->n, h->alpha.present, h->stream));
   h->eos_code = h->alpha.nch[(uint8_t)h->cfg.eos];                  // shift_and_inexact.cc:131
   int rc = resolve(h);
   if (rc) return rc;
@@ -955,7 +959,8 @@ extern "C" int pm_align_hits_text(pm_handle *h, const pm_hit *hits, size_t n, pm
 
 static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride) {
   if (!h || !h->inited || (!hits && n) || (!out && n)) return fail(h, PM_E_INVALID, "pm_align_hits: bad arguments");
-  if (ops && h->cfg.wildcards) return fail(h, PM_E_UNSUPPORTED, "pm_align_hits_text: wildcard alignments (exact_wc_alignment) are not built");
+  if (ops && h->cfg.wildcards && h->cfg.k > 0) return fail(h, PM_E_UNSUPPORTED, "pm_align_hits_text: wildcard alignments with k > 0 are not built");
+  const bool wc_exact = h->cfg.wildcards && h->cfg.k == 0;      // exact_wc_alignment (pattern_alignment.cc:70-93) reads the text
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int k = h->cfg.k;
   std::vector<Window> wins(n);
@@ -967,12 +972,34 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
     const int L = (int)pp[i]->s.size();
     int64_t ws = 0;
     if (hits[i].end > (int64_t)L + k) ws = hits[i].end - L - k;       // pattern_alignment.cc:137-139
-    wins[i] = Window{ws, k == 0 ? 0 : (int32_t)(hits[i].end - ws), 0};
+    wins[i] = Window{ws, (k == 0 && !wc_exact) ? 0 : (int32_t)(hits[i].end - ws), 0};
   }
-  if (k > 0) { int rc = fetch_windows(h, wins); if (rc) return rc; }
+  if (k > 0 || wc_exact) { int rc = fetch_windows(h, wins); if (rc) return rc; }
   AlignParams prm; prm.k = k; prm.indels = h->cfg.indels != 0; prm.eos = (uint8_t)h->cfg.eos;
   for (size_t i = 0; i < n; ++i) {
     const int L = (int)pp[i]->s.size();
+    if (wc_exact) {
+      // start = end - L; per character: equal, IUPAC-compatible (text N only with -W), or substitution
+      const int64_t st = hits[i].end - L;
+      if ((size_t)L + 1 > stride && ops) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
+      int subs = 0;
+      for (int q = 0; q < L; ++q) {
+        const int64_t tp = st + q;
+        const unsigned char tc = tp >= wins[i].start && tp < hits[i].end ? h->winbuf[wins[i].off + (tp - wins[i].start)] : 0;
+        const unsigned char pc = (unsigned char)pp[i]->s[q];
+        char op;
+        if (tc == pc) op = '|';
+        else {
+          const char *set = tc < 128 ? iupac_compatible_set(tc) : nullptr;
+          if (set && pc && strchr(set, pc) && (h->cfg.text_n || tc != 'N')) op = '+';
+          else { op = '*'; ++subs; }
+        }
+        if (ops) { ops[i * stride + q] = op; text[i * stride + q] = (char)tc; }
+      }
+      if (ops) { ops[i * stride + L] = 0; text[i * stride + L] = 0; }
+      out[i].start = st; out[i].end = hits[i].end; out[i].editdist = subs; out[i].value = 0;
+      continue;
+    }
     if (k == 0) {                                                    // exact_alignment (pattern_alignment.cc:29-43)
       out[i].start = hits[i].end - L; out[i].end = hits[i].end; out[i].editdist = 0; out[i].value = 0;
       if (ops) {

@@ -221,7 +221,7 @@ std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uin
     if (set) {
       for (const char *q = set; *q; ++q) {
         const int code = alpha.nch[(unsigned char)*q];
-        if (code >= 0 && code < alpha.size && (*q != 'N' || text_n)) {
+        if (code >= 0 && code < alpha.size && alpha.present[code] && (*q != 'N' || text_n)) {
           bool dup = false;
           for (int i = 0; i < nc; ++i) dup = dup || codes[i] == code;
           if (!dup) codes[nc++] = code;

@@ -22,6 +22,7 @@ struct Alphabet {
   int     size = 256;
   uint8_t ch[256];
   int     nch[256];
+  bool    present[256];     // false: the code is known not to occur in the stream (only narrowed for raw streams with -w/-W)
   void set_raw();
   void set_table(const uint8_t *table, int len);
 };
@@ -68,6 +69,9 @@ hipError_t bitpar_launch(const BitparDevice &d, const uint8_t *d_text, int64_t n
                          pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
                          ScanGeometry *geo_out);
 const char *bitpar_kernel_name(int k, bool indels);
+
+// which byte values occur in the stream (pm_util.hip); used to bound the character classes of -w/-W on raw streams
+hipError_t stream_presence(const uint8_t *d_text, int64_t n, bool present[256], hipStream_t st);
 
 // ---- window gather (verify stage text access when the stream lives only in HBM) -------------
 hipError_t gather_windows(const uint8_t *d_text, int64_t n, const int64_t *d_starts, const int32_t *d_lens,

@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #include "../../include/pm_gpu.h"
+#include "pm_internal.h"
 
 namespace {
 
@@ -31,7 +32,48 @@ __global__ __launch_bounds__(256) void pm_stream_read(const u32x4 *p, size_t n16
   if (acc == 0x9e3779b9u && sink) sink[0] = acc;                  // keeps the loads alive; practically never taken
 }
 
+// which byte values occur in the stream: 256 flags (as 8 dwords), OR-reduced through LDS
+__global__ __launch_bounds__(256) void pm_stream_presence(const uint8_t *p, size_t n, uint32_t *flags) {
+  __shared__ uint32_t s[8];
+  if (threadIdx.x < 8) s[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint32_t b = p[i];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) loc[w] |= (b >> 5) == (uint32_t)w ? 1u << (b & 31) : 0u;
+  }
+#pragma unroll
+  for (int w = 0; w < 8; ++w) if (loc[w]) atomicOr(&s[w], loc[w]);
+  __syncthreads();
+  if (threadIdx.x < 8 && s[threadIdx.x]) atomicOr(&flags[threadIdx.x], s[threadIdx.x]);
+}
+
 }  // namespace
+
+namespace pm {
+
+hipError_t stream_presence(const uint8_t *d_text, int64_t n, bool present[256], hipStream_t st) {
+  for (int i = 0; i < 256; ++i) present[i] = false;
+  if (n <= 0) return hipSuccess;
+  uint32_t *d = nullptr;
+  hipError_t e = hipMalloc((void **)&d, 32);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d, 0, 32, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(pm_stream_presence, dim3(256 * 8), dim3(256), 0, st, d_text, (size_t)n, d);
+    e = hipGetLastError();
+  }
+  uint32_t hflags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(hflags, d, 32, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  for (int i = 0; i < 256; ++i) present[i] = (hflags[i >> 5] >> (i & 31)) & 1u;
+  return e;
+}
+
+}  // namespace pm
 
 extern "C" int pm_measure_stream_read(const void *d_buf, size_t bytes, int reps, void *stream, float *gbytes_per_s) {
   if (!d_buf || bytes < 16 || reps < 1 || !gbytes_per_s) return PM_E_INVALID;

@@ -46,6 +46,9 @@ CASES = [
     ("k1_sts_primers", "S", ["-k", "1", "-A", "%I %L %a [%O] %& %X %i %r %e %d\\n", "-C", "%I %L %i %r %c\\n"]),
     ("k0_inline_primers", "p", ["-r", "-A", "%i %r %s %e\\n"]),
     ("k1_report_interval", "P", ["-r", "-k", "1", "-R", "3", "-A", "%i %r %e %d\\n"]),
+    ("k0_wildcards", "W", ["-r", "-w", "-A", ONE_LINE]),
+    ("k0_wildcards_text_n", "W", ["-r", "-W", "-A", ONE_LINE]),
+    ("k0_wildcards_counts", "W", ["-r", "-W", "-c"]),
 ]
 
 
@@ -87,7 +90,32 @@ def build_inputs(seed):
     for i in range(0, len(pats) - 1, 2):
         size = "150" if i % 4 == 0 else "100-%d" % (200 + i)
         sts_lines.append("STS%d\t%s\t%s\t%s\tACC%d\t%d\tALT%d\tHomo sapiens" % (i, pats[i], pats[i + 1], size, i, i % 23 + 1, i))
-    return fasta, ptxt, pfa, "\n".join(sts_lines) + "\n", pats
+    # IUPAC primers for -w / -W: planted sites with some bases widened to ambiguity codes, one site
+    # that covers an N run of the database (matches only with -W), one unrelated primer
+    widen = {"A": "RMWN", "C": "YMSN", "G": "RKSN", "T": "YKWN"}
+    wpats = []
+    for _ in range(8):
+        L = int(rng.integers(16, 23))
+        e = int(rng.integers(0, 4))
+        a = int(rng.integers(0, len(ents[e]) - L))
+        w = list(ents[e][a:a + L])
+        if "N" in w:
+            continue
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.integers(0, L))
+            w[i] = str(rng.choice(list(widen.get(w[i], w[i]))))
+        w = "".join(w)
+        wpats.append(synth.revcomp_iupac(w) if int(rng.integers(0, 2)) else w)
+    for e in range(4):
+        i = ents[e].find("N")
+        if i > 12 and i + 12 < len(ents[e]):
+            site = ents[e][i - 10:i + 10]
+            wpats.append("".join(c if c != "N" else "A" for c in site))
+            wpats.append(site)                                              # pattern N against text N
+            break
+    wpats.append("ACGTRYKMACGTRYKMACGT")
+    wtxt = "\n".join(wpats) + "\n"
+    return fasta, ptxt, pfa, "\n".join(sts_lines) + "\n", pats, wtxt
 
 
 def run(cmd, **kw):
@@ -96,8 +124,8 @@ def run(cmd, **kw):
 
 def main():
     for name, seed in [("cli_a", 11), ("cli_b", 12)]:
-        fasta, ptxt, pfa, psts, pats = build_inputs(seed)
-        out = {"fasta": fasta, "primers_txt": ptxt, "primers_fasta": pfa, "primers_sts": psts, "cases": {}, "db_files": {}}
+        fasta, ptxt, pfa, psts, pats, wtxt = build_inputs(seed)
+        out = {"fasta": fasta, "primers_txt": ptxt, "primers_fasta": pfa, "primers_sts": psts, "primers_iupac": wtxt, "cases": {}, "db_files": {}}
         with tempfile.TemporaryDirectory() as d:
             fa = os.path.join(d, "db.fa")
             for variant, args in [("normalized", ["-n", "true"]), ("indexed", [])]:
@@ -114,13 +142,13 @@ def main():
                         with open(fa + "." + ext, "rb") as f:
                             files[ext] = base64.b64encode(f.read()).decode()
                 out["db_files"][variant] = files
-            for src, text in (("P", ptxt), ("F", pfa), ("S", psts)):
+            for src, text in (("P", ptxt), ("F", pfa), ("S", psts), ("W", wtxt)):
                 with open(os.path.join(d, "primers." + src), "w") as f:
                     f.write(text)
             for cname, src, extra in CASES:
                 for variant in ("normalized", "indexed"):
                     fa = os.path.join(d, variant, "db.fa")
-                    parg = ["-p", " ".join(pats[:5])] if src == "p" else ["-" + src, os.path.join(d, "primers." + src)]
+                    parg = ["-p", " ".join(pats[:5])] if src == "p" else ["-" + ("P" if src == "W" else src), os.path.join(d, "primers." + src)]
                     r = run([os.path.join(REF, "primer_match"), "-i", fa] + parg + extra)
                     assert r.returncode == 0, (cname, r.stderr[-500:])
                     out["cases"].setdefault(cname, {"primers": src, "options": extra})[variant] = r.stdout.decode("latin1")

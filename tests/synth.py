@@ -13,6 +13,13 @@ def revcomp(p):
     return "".join(COMP.get(c, c) for c in reversed(p))
 
 
+IUPAC_COMP = dict(COMP, M="K", K="M", R="Y", Y="R", V="B", B="V", H="D", D="H", W="W", S="S", U="A")
+
+
+def revcomp_iupac(p):
+    return "".join(IUPAC_COMP.get(c, c) for c in reversed(p))
+
+
 def make_entries(rng, n_entries, length, n_runs=0, repeats=False, short=False):
     """List of DNA strings: uniform ACGT, optional N runs, tandem repeats and a too-short entry."""
     ents = []

@@ -30,7 +30,7 @@ def prepare(g, d):
             f.write(g["fasta"])
         r = subprocess.run([CS, "-i", fa] + args, capture_output=True)
         assert r.returncode == 0, r.stderr
-    for src, key in (("P", "primers_txt"), ("F", "primers_fasta"), ("S", "primers_sts")):
+    for src, key in (("P", "primers_txt"), ("F", "primers_fasta"), ("S", "primers_sts"), ("W", "primers_iupac")):
         with open(os.path.join(d, "primers." + src), "w") as f:
             f.write(g[key])
 
@@ -41,7 +41,7 @@ def run_case(g, d, case, variant, more=()):
     if c["primers"] == "p":
         parg = ["-p", " ".join(g["primers_txt"].split()[:5])]
     else:
-        parg = ["-" + c["primers"], os.path.join(d, "primers." + c["primers"])]
+        parg = ["-" + ("P" if c["primers"] == "W" else c["primers"]), os.path.join(d, "primers." + c["primers"])]
     r = subprocess.run([PM, "-i", fa] + parg + c["options"] + list(more), capture_output=True, timeout=300)
     assert r.returncode == 0, (case, r.stderr[-500:])
     return r.stdout.decode("latin1")
