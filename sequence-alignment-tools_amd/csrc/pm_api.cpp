@@ -722,10 +722,41 @@ bool seed_order(const pm_hit &a, const pm_hit &b) {                  // exact_ha
   return a.pid > b.pid;
 }
 
+// Sort records into seed_order.  std::sort on 16-byte records was most of the host stage
+// (5 ms per 80k records); positions < 2^40 and ids < 2^24 make one 64-bit key, sorted by an LSD
+// radix sort of (key, index) pairs.
+void sort_seed_order(std::vector<pm_hit> &v) {
+  const size_t n = v.size();
+  bool fits = n < ((size_t)1 << 31);
+  for (size_t i = 0; i < n && fits; ++i) fits = v[i].end >= 0 && v[i].end < ((int64_t)1 << 40) && v[i].pid < (1u << 24);
+  if (!fits || n < 64) { std::sort(v.begin(), v.end(), seed_order); return; }
+  struct KI { uint64_t key; uint32_t idx; };
+  std::vector<KI> a(n), b(n);
+  uint64_t all_or = 0;
+  for (size_t i = 0; i < n; ++i) {
+    a[i].key = ((uint64_t)v[i].end << 24) | (uint64_t)(0xffffffu - v[i].pid);   // id descending
+    a[i].idx = (uint32_t)i;
+    all_or |= a[i].key;
+  }
+  constexpr int BITS = 11;
+  std::vector<uint32_t> cnt((size_t)1 << BITS);
+  for (int shift = 0; shift < 64 && (all_or >> shift) != 0; shift += BITS) {
+    std::fill(cnt.begin(), cnt.end(), 0u);
+    for (size_t i = 0; i < n; ++i) ++cnt[(a[i].key >> shift) & ((1u << BITS) - 1)];
+    uint32_t run = 0;
+    for (uint32_t &c : cnt) { const uint32_t t = c; c = run; run += t; }
+    for (size_t i = 0; i < n; ++i) b[cnt[(a[i].key >> shift) & ((1u << BITS) - 1)]++] = a[i];
+    a.swap(b);
+  }
+  std::vector<pm_hit> out(n);
+  for (size_t i = 0; i < n; ++i) out[i] = v[a[i].idx];
+  v.swap(out);
+}
+
 // exact_halves::find_patterns (exact_halves.cc:140-190) / exact_bases (exact_bases.cc:92-121)
 int finalize_seeds(pm_handle *h, const pm_hit *cands, size_t n, bool halves, std::vector<pm_hit> &outv) {
   std::vector<pm_hit> seeds(cands, cands + n);
-  if (halves) std::sort(seeds.begin(), seeds.end(), seed_order);
+  if (halves) sort_seed_order(seeds);
   else std::sort(seeds.begin(), seeds.end(), by_end_pid);
   const int k = h->cfg.k;
   const bool indels = h->cfg.indels != 0;
@@ -794,7 +825,7 @@ int finalize_halves_flags(pm_handle *h, const pm_hit *cands, size_t n, int64_t s
     if (cands[i].aux[0] & 1) { pm_hit x = make_hit(cands[i].end - len2, 2 * j - 1, cands[i].k); x.aux[0] = (uint8_t)len2; seeds.push_back(x); }
     if (cands[i].aux[0] & 2) seeds.push_back(make_hit(cands[i].end, 2 * j, cands[i].k));
   }
-  std::sort(seeds.begin(), seeds.end(), seed_order);
+  sort_seed_order(seeds);
   // candidates still to come end beyond scanned_to, so their seeds lie beyond scanned_to - maxlen:
   // everything at or before that is in its final order
   const int64_t safe = last ? INT64_MAX : scanned_to - h->sd.maxlen;
@@ -817,7 +848,7 @@ int finalize_halves_flags(pm_handle *h, const pm_hit *cands, size_t n, int64_t s
 // desc) order, a hit is kept if its end exceeds the pattern's last kept end by more than 2k.
 int finalize_extended(pm_handle *h, const pm_hit *cands, size_t n, std::vector<pm_hit> &outv) {
   std::vector<pm_hit> seeds(cands, cands + n);
-  std::sort(seeds.begin(), seeds.end(), seed_order);
+  sort_seed_order(seeds);
   const int slack = h->cfg.indels ? 2 * h->cfg.k : 0;
   for (const pm_hit &s : seeds) {
     const uint32_t j = (s.pid + 1) / 2;
