@@ -77,7 +77,7 @@ typedef struct {
   int32_t kernel;          /* pm_kernel */
   int32_t k;               /* -k / -K value */
   int32_t indels;          /* 1 = -k (edits), 0 = -K (substitutions only) */
-  int32_t wildcards;       /* -w/-W: IUPAC pattern classes; exact search only (k > 0: PM_E_UNSUPPORTED) */
+  int32_t wildcards;       /* -w/-W: IUPAC pattern classes (bit-parallel kernel family) */
   int32_t text_n;          /* -W: a text N also matches (shift_and.cc:112) */
   int32_t eos;             /* raw end-of-sequence char, '\n' in the CLIs */
   int32_t device;          /* HIP device ordinal */

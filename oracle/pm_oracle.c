@@ -229,8 +229,14 @@ static int run_shift_and_inexact(const pmo_text *t, const pat_t *p, int np, int 
 /* ------------------------------------------------------------------------------------------ */
 /* editdist_alignment::align  (pattern_alignment.cc:117-705)                                   */
 
-enum { F_EQ = 2, F_SUB = 8, F_INS = 16, F_DEL = 32, F_VIOL = 64, F_END = 128 };
-enum { AC_NONE = 0, AC_EQ = 1, AC_SUB = 3, AC_INS = 4, AC_DEL = 5, AC_VIOL = 6 };
+enum { F_EQ = 2, F_WEQ = 4, F_SUB = 8, F_INS = 16, F_DEL = 32, F_VIOL = 64, F_END = 128 };
+enum { AC_NONE = 0, AC_EQ = 1, AC_WEQ = 2, AC_SUB = 3, AC_INS = 4, AC_DEL = 5, AC_VIOL = 6 };
+
+/* iupac_compatible(w, c) (util.cc:164-183): c is listed in w's compatibility string */
+static int iupac_pair(uint8_t w, uint8_t c) {
+  const char *set = w < 128 ? iupac_set(w) : 0;
+  return set && c && strchr(set, (char)c) != 0;
+}
 
 /* Banded DP filled right to left: row p = last p pattern chars, column t = last t chars of the
  * window [textstart, end2) with textstart = max(0, end - L - k) (:137-148).  Row 0 is free for
@@ -282,6 +288,7 @@ int pmo_editdist_align(const pmo_text *t, const char *pat, int L, int64_t end, i
       const uint8_t tc = buf[buflen - tt];
       unsigned v, v1; int ac;
       if (tc == pc) { v = D(p - 1, tt - 1); ac = F_EQ; }
+      else if (g_wc && iupac_pair(pc, tc) && (tc != 'N' || g_tn)) { v = D(p - 1, tt - 1); ac = F_WEQ; }   /* :317-319 */
       else if (tc == eos || pc == eos || p_exact_sub) { v = (unsigned)viol; ac = F_VIOL; }
       else { v = D(p - 1, tt - 1) + 1; ac = F_SUB; }
       if (tc == eos || pc == eos || !indels || tt <= lb || p_exact_ins) {
@@ -312,7 +319,7 @@ int pmo_editdist_align(const pmo_text *t, const char *pat, int L, int64_t end, i
     ub = L + delta + b; if (buflen < ub) ub = buflen;
     for (int c = beststart + 1; c <= ub; c++) {
       int v = (int)D(L, c);
-      if (v < bestval || (v <= bestval && (B(L, c) & (F_EQ | F_SUB)))) { bestval = v; beststart = c; }
+      if (v < bestval || (v <= bestval && (B(L, c) & (F_EQ | F_WEQ | F_SUB)))) { bestval = v; beststart = c; }
     }
     int p = L, tt = beststart;
     if (tt < p - b || tt > p + b + delta) { out->editdist = INT32_MAX; goto done; }   /* :482-490 */
@@ -321,10 +328,11 @@ int pmo_editdist_align(const pmo_text *t, const char *pat, int L, int64_t end, i
     int lastac = AC_NONE, nsub = 0, nins = 0, ndel = 0, nviol = 0;
     while (!(B(p, tt) & F_END)) {
       int ac = B(p, tt);
-      int match = ac & (F_EQ | F_SUB), sub = ac & F_SUB, ins = ac & F_INS, del = ac & F_DEL;
-      if (match && !((lastac == AC_INS && ins) || (lastac == AC_DEL && del))) {
+      int match = ac & (F_EQ | F_WEQ | F_SUB), wcf = ac & F_WEQ, sub = ac & F_SUB, ins = ac & F_INS, del = ac & F_DEL;
+      if (match && !((lastac == AC_INS && ins) || (lastac == AC_DEL && del) || (lastac == AC_WEQ && !wcf && (ins || del)))) {
         p--; tt--;
-        if ((ac & F_EQ) && !(lastac == AC_SUB && sub)) lastac = AC_EQ;
+        if ((ac & F_EQ) && !((lastac == AC_WEQ && wcf) || (lastac == AC_SUB && sub))) lastac = AC_EQ;
+        else if (wcf) lastac = AC_WEQ;
         else if (sub) lastac = AC_SUB;
       } else if (del) { p--; lastac = AC_DEL; }
       else if (ins) { tt--; lastac = AC_INS; }
@@ -526,6 +534,7 @@ static int global_align(const uint8_t *text, int textlen, const char *pat, int L
       const uint8_t tc = dirn > 0 ? text[tt - 1] : text[textlen - tt];
       int v, v1, ac, ac1;
       if (tc == pc) { v = (int)D(p - 1, tt - 1); ac = F_EQ; }
+      else if (g_wc && iupac_pair(tc, pc) && (g_tn || tc != 'N')) { v = (int)D(p - 1, tt - 1); ac = F_WEQ; }   /* primer_alignment.cc:151-154 */
       else if (tc == eos || pc == eos || p <= lbexact || p >= rbexact) { v = viol; ac = F_VIOL; }
       else { v = (int)D(p - 1, tt - 1) + 1; ac = F_SUB; }
       if (tc == eos || pc == eos || !indels || tt <= lb || p < lbexact || p >= rbexact) { v1 = viol; ac1 = F_VIOL; }
@@ -547,7 +556,7 @@ static int global_align(const uint8_t *text, int textlen, const char *pat, int L
     ub = L + b; if (textlen < ub) ub = textlen;
     for (int c = bestpos + 1; c <= ub; c++) {
       int v = (int)D(L, c);
-      if (v < bestval || (v <= bestval && (B(L, c) & (F_EQ | F_SUB)))) { bestval = v; bestpos = c; }
+      if (v < bestval || (v <= bestval && (B(L, c) & (F_EQ | F_WEQ | F_SUB)))) { bestval = v; bestpos = c; }
     }
     if (bestpos < L - b || bestpos > L + b) goto done;             /* :285-289 */
     *matchlen = bestpos; *value = bestval;                         /* yesno, :290-299 */
@@ -715,7 +724,7 @@ int pmo_pick_engine(const pmo_text *t, int k, int indels, int wildcards, int npa
 int pmo_find_all(const pmo_text *t, const pmo_config *cfg,
                  const char *patbuf, const int64_t *patoff, int npat, const uint32_t *ids,
                  const int32_t *esb, const int32_t *eeb, pmo_hit **out, size_t *nout) {
-  if (cfg->wildcards && (cfg->k > 0 || (cfg->engine != PMO_SHIFT_AND && cfg->engine != PMO_AUTO))) return -3;   /* -w: exact shift_and only */
+  if (cfg->wildcards && (cfg->engine >= 1 && cfg->engine <= 3)) return -3;   /* keyword trees know no IUPAC classes (select.cc:101-102 picks shift_and) */
   g_wc = cfg->wildcards; g_tn = cfg->text_n;
   pat_t *p = (pat_t *)malloc(sizeof(pat_t) * (size_t)(npat ? npat : 1));
   int32_t *plen = (int32_t *)malloc(sizeof(int32_t) * (size_t)(npat ? npat : 1));
@@ -749,9 +758,19 @@ int pmo_find_all(const pmo_text *t, const pmo_config *cfg,
 
 int pmo_cli_align(const pmo_text *t, const pmo_config *cfg, const char *pat, int patlen,
                   int esb, int eeb, int64_t end, pmo_alignment *out) {
-  if (cfg->k == 0) {                 /* exact_alignment (pattern_alignment.cc:29-43) */
+  g_wc = cfg->wildcards; g_tn = cfg->text_n;
+  if (cfg->k == 0 && !cfg->wildcards) {   /* exact_alignment (pattern_alignment.cc:29-43) */
     out->start = end - patlen; out->end = end; out->editdist = 0; out->value = 0;
     return 1;
+  }
+  if (cfg->k == 0) {                 /* exact_wc_alignment (pattern_alignment.cc:70-93) */
+    int subs = 0;
+    for (int i = 0; i < patlen; i++) {
+      const uint8_t tc = text_char(t, end - patlen + i), pc = (uint8_t)pat[i];
+      if (tc != pc && !(iupac_pair(tc, pc) && (g_tn || tc != 'N'))) subs++;
+    }
+    out->start = end - patlen; out->end = end; out->editdist = subs; out->value = 0;
+    return subs <= 0;
   }
   /* editdist_alignment(key,key,k,eos,wc,tn,indels,dm,esb,eeb,false) (primer_match.cc:1143-1149) */
   return pmo_editdist_align(t, pat, patlen, end, end, cfg->k, cfg->eos, cfg->indels, esb, eeb, 0, out);

@@ -119,8 +119,8 @@ def pick_engine(text, patterns, k, indels=True, esb=None, eeb=None):
                                  C.c_int(len(patterns)), pl.ctypes.data_as(C.c_void_p), a(esb), a(eeb))
 
 
-def cli_align(text, pattern, end, k, indels=True, eos=10, esb=0, eeb=0):
-    cfg = _cfg(0, k, indels, eos)
+def cli_align(text, pattern, end, k, indels=True, eos=10, esb=0, eeb=0, wildcards=False, text_n=False):
+    cfg = _cfg(0, k, indels, eos, wildcards, text_n)
     al = _Alignment()
     pb = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
     rc = lib().pmo_cli_align(C.byref(text._t), C.byref(cfg), pb, C.c_int(len(pb)), C.c_int(esb), C.c_int(eeb),

@@ -5,12 +5,21 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstring>
+
+#include "pm_iupac.h"
 
 namespace pm {
 namespace {
 
-enum : uint16_t { EQ = 2, SUB = 8, INS = 16, DEL = 32, VIOL = 64, END = 128 };
-enum Step { S_NONE, S_EQ, S_SUB, S_INS, S_DEL, S_VIOL };
+enum : uint16_t { EQ = 2, WEQ = 4, SUB = 8, INS = 16, DEL = 32, VIOL = 64, END = 128 };
+enum Step { S_NONE, S_EQ, S_WEQ, S_SUB, S_INS, S_DEL, S_VIOL };
+
+// iupac_compatible(w, c) (reference util.cc:164-183): c is listed in w's compatibility string
+inline bool iupac_pair(uint8_t w, uint8_t c) {
+  const char *set = w < 128 ? iupac_compatible_set(w) : nullptr;
+  return set && c && strchr(set, (char)c) != nullptr;
+}
 
 struct Band {
   uint32_t *dp; uint16_t *fl; int W, b;
@@ -64,6 +73,7 @@ AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, i
       const uint8_t tc = win[buflen - t];
       uint32_t v, v1; uint16_t ac;
       if (tc == pc) { v = B.dp[B.at(p - 1, t - 1)]; ac = EQ; }
+      else if (prm.wc && iupac_pair(pc, tc) && (tc != 'N' || prm.tn)) { v = B.dp[B.at(p - 1, t - 1)]; ac = WEQ; }   // :317-319
       else if (tc == eos || pc == eos || zone_sub) { v = (uint32_t)viol; ac = VIOL; }
       else { v = B.dp[B.at(p - 1, t - 1)] + 1; ac = SUB; }
       if (tc == eos || pc == eos || !prm.indels || t <= lb || zone_ins) {
@@ -88,7 +98,7 @@ AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, i
   int bestval = (int)B.dp[B.at(L, best)];
   for (int c = best + 1, ub = std::min(buflen, L + delta + b); c <= ub; ++c) {
     const int v = (int)B.dp[B.at(L, c)];
-    if (v < bestval || (v <= bestval && (B.fl[B.at(L, c)] & (EQ | SUB)))) { bestval = v; best = c; }
+    if (v < bestval || (v <= bestval && (B.fl[B.at(L, c)] & (EQ | WEQ | SUB)))) { bestval = v; best = c; }
   }
   int p = L, t = best;
   if (t < p - b || t > p + b + delta) return r;           // :482-490
@@ -96,10 +106,11 @@ AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, i
   int nsub = 0, nins = 0, ndel = 0, nviol = 0;
   while (!(B.fl[B.at(p, t)] & END)) {                     // traceback (:514-590)
     const uint16_t ac = B.fl[B.at(p, t)];
-    const bool match = ac & (EQ | SUB), sub = ac & SUB, ins = ac & INS, del = ac & DEL;
-    if (match && !((last == S_INS && ins) || (last == S_DEL && del))) {
+    const bool match = ac & (EQ | WEQ | SUB), wcf = ac & WEQ, sub = ac & SUB, ins = ac & INS, del = ac & DEL;
+    if (match && !((last == S_INS && ins) || (last == S_DEL && del) || (last == S_WEQ && !wcf && (ins || del)))) {
       --p; --t;
-      if ((ac & EQ) && !(last == S_SUB && sub)) last = S_EQ;
+      if ((ac & EQ) && !((last == S_WEQ && wcf) || (last == S_SUB && sub))) last = S_EQ;
+      else if (wcf) last = S_WEQ;
       else if (sub) { last = S_SUB; }
       if (last == S_SUB) ++nsub;
     } else if (del) { --p; last = S_DEL; ++ndel; }
@@ -107,7 +118,7 @@ AlignResult editdist_align(const uint8_t *win, int64_t win_start, int64_t end, i
     else if (ac & VIOL) { p = 0; t = 0; last = S_VIOL; ++nviol; }
     else return r;
     // pattern_alignment::alignment_string's characters (pattern_alignment.h:122-165), pattern start first
-    if (ops) ops->push_back(last == S_EQ ? '|' : last == S_SUB ? '*' : last == S_INS ? '^' : last == S_DEL ? 'v' : '!');
+    if (ops) ops->push_back(last == S_EQ ? '|' : last == S_WEQ ? '+' : last == S_SUB ? '*' : last == S_INS ? '^' : last == S_DEL ? 'v' : '!');
   }
   r.start = end2 - best;                                  // :603-610
   r.end = end2 - t;
@@ -149,6 +160,7 @@ bool global_align(const uint8_t *text, int textlen, const char *pat, int L, int 
       const uint8_t tc = dirn > 0 ? text[t - 1] : text[textlen - t];
       int v, v1; uint16_t ac, ac1;
       if (tc == pc) { v = (int)B.dp[B.at(p - 1, t - 1)]; ac = EQ; }
+      else if (prm.wc && iupac_pair(tc, pc) && (prm.tn || tc != 'N')) { v = (int)B.dp[B.at(p - 1, t - 1)]; ac = WEQ; }   // primer_alignment.cc:151-154
       else if (tc == eos || pc == eos || p <= lbexact || p >= rbexact) { v = viol; ac = VIOL; }
       else { v = (int)B.dp[B.at(p - 1, t - 1)] + 1; ac = SUB; }
       if (tc == eos || pc == eos || !prm.indels || t <= lb || p < lbexact || p >= rbexact) { v1 = viol; ac1 = VIOL; }
@@ -167,7 +179,7 @@ bool global_align(const uint8_t *text, int textlen, const char *pat, int L, int 
   int bestval = (int)B.dp[B.at(L, best)];
   for (int c = best + 1, ub = std::min(textlen, L + b); c <= ub; ++c) {
     const int v = (int)B.dp[B.at(L, c)];
-    if (v < bestval || (v <= bestval && (B.fl[B.at(L, c)] & (EQ | SUB)))) { bestval = v; best = c; }
+    if (v < bestval || (v <= bestval && (B.fl[B.at(L, c)] & (EQ | WEQ | SUB)))) { bestval = v; best = c; }
   }
   if (best < L - b || best > L + b) return false;         // :285-289
   *matchlen = best; *value = bestval;

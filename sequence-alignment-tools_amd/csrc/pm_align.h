@@ -24,6 +24,7 @@ struct AlignParams {
   int     k = 0;
   bool    indels = true;
   uint8_t eos = '\n';
+  bool    wc = false, tn = false;   // -w / -W: IUPAC-compatible characters cost nothing; text N only with tn
 };
 
 // Reusable scratch so the verify loop does not allocate per candidate.

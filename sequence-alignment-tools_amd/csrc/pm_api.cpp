@@ -138,8 +138,6 @@ extern "C" int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized,
 extern "C" int pm_create(const pm_config *cfg, pm_handle **out) {
   if (!cfg || !out) return fail(nullptr, PM_E_INVALID, "pm_create: null argument");
   if (cfg->abi_version != PM_ABI_VERSION) return fail(nullptr, PM_E_INVALID, "pm_create: ABI version mismatch");
-  if (cfg->wildcards && cfg->k > 0)
-    return fail(nullptr, PM_E_UNSUPPORTED, "IUPAC wildcard matching (-w/-W) is implemented for exact search (k = 0) only");
   if (cfg->k < 0) return fail(nullptr, PM_E_INVALID, "pm_create: negative k");
   pm_handle *h = new (std::nothrow) pm_handle();
   if (!h) return fail(nullptr, PM_E_NOMEM, "out of memory");
@@ -707,6 +705,7 @@ int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
   int rc = fetch_windows(h, wins);
   if (rc) return rc;
   AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
+  prm.wc = h->cfg.wildcards != 0; prm.tn = h->cfg.text_n != 0;
   for (size_t wi = 0; wi < need_dp.size(); ++wi) {
     const Cluster &c = need_dp[wi];
     const Pattern &p = h->pats[c.pid - 1];
@@ -789,6 +788,7 @@ int finalize_seeds(pm_handle *h, const pm_hit *cands, size_t n, bool halves, std
   int rc = fetch_windows(h, wins);
   if (rc) return rc;
   AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
+  prm.wc = h->cfg.wildcards != 0; prm.tn = h->cfg.text_n != 0;
   for (size_t i = 0; i < seeds.size(); ++i) {
     const Job &j = jobs[i];
     const Pattern &p = h->pats[j.pat];
@@ -990,7 +990,6 @@ extern "C" int pm_align_hits_text(pm_handle *h, const pm_hit *hits, size_t n, pm
 
 static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride) {
   if (!h || !h->inited || (!hits && n) || (!out && n)) return fail(h, PM_E_INVALID, "pm_align_hits: bad arguments");
-  if (ops && h->cfg.wildcards && h->cfg.k > 0) return fail(h, PM_E_UNSUPPORTED, "pm_align_hits_text: wildcard alignments with k > 0 are not built");
   const bool wc_exact = h->cfg.wildcards && h->cfg.k == 0;      // exact_wc_alignment (pattern_alignment.cc:70-93) reads the text
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const int k = h->cfg.k;
@@ -1007,6 +1006,7 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
   }
   if (k > 0 || wc_exact) { int rc = fetch_windows(h, wins); if (rc) return rc; }
   AlignParams prm; prm.k = k; prm.indels = h->cfg.indels != 0; prm.eos = (uint8_t)h->cfg.eos;
+  prm.wc = h->cfg.wildcards != 0; prm.tn = h->cfg.text_n != 0;
   for (size_t i = 0; i < n; ++i) {
     const int L = (int)pp[i]->s.size();
     if (wc_exact) {

@@ -8,7 +8,7 @@
 // one FASTA entry with length in [-m, -M] (and within -d of the UniSTS size) and prints them
 // through the -A format language (pcr_match.cc:339-686).
 //
-// Not built (refused with a message): wildcard alignments with k > 0, raw FASTA / .sqz databases.
+// Not built (refused with a message): raw FASTA / .sqz databases.
 #include <unistd.h>
 
 #include <chrono>
@@ -110,7 +110,6 @@ Options parse(int argc, char **argv) {
   if (o.nmismatch < 0) usage("Number of mismatches (-k) must be at least 0");
   if (o.dbind < 0 || o.dbind > 4) usage("Invalid integer for fasta database indexing (-D).");
   if (o.dbind == 1 || o.dbind == 4) usage("Only indexed (-D 2) and normalized (-D 3) databases are supported; run pm_compress_seq first.");
-  if (o.wc && o.nmismatch > 0) usage("Wildcard alignments with k > 0 are not available on the GPU engine.");
   return o;
 }
 

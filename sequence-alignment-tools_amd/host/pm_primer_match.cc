@@ -7,8 +7,8 @@
 // pick_pattern_index returns, every hit is re-aligned (pm_align_hits_text = exact_alignment /
 // editdist_alignment) and printed through the -A / -C mini-languages (primer_match.cc:355-843).
 //
-// Not built (refused with a message): -T (translation), DNA-mutation scoring (-k .N), wildcard
-// alignments with k > 0, raw FASTA / .sqz databases (-D 1, -D 4; run pm_compress_seq first),
+// Not built (refused with a message): -T (translation), DNA-mutation scoring (-k .N),
+// raw FASTA / .sqz databases (-D 1, -D 4; run pm_compress_seq first),
 // the PRIMER3TM escapes %m %G and the peptide-mass escape %M.
 #include <unistd.h>
 

@@ -49,6 +49,9 @@ CASES = [
     ("k0_wildcards", "W", ["-r", "-w", "-A", ONE_LINE]),
     ("k0_wildcards_text_n", "W", ["-r", "-W", "-A", ONE_LINE]),
     ("k0_wildcards_counts", "W", ["-r", "-W", "-c"]),
+    ("k1_wildcards", "W", ["-r", "-w", "-k", "1", "-A", ONE_LINE]),
+    ("K2_wildcards_text_n", "W", ["-r", "-W", "-K", "2", "-A", ONE_LINE]),
+    ("k2_wildcards_default", "W", ["-r", "-W", "-k", "2"]),
 ]
 
 

@@ -265,8 +265,7 @@ def test_pattern_tiling_gives_identical_hits(monkeypatch):
 
 @pytest.mark.parametrize("seed", range(3))
 def test_iupac_wildcards_exact(seed):
-    """-w / -W exact search (shift_and with IUPAC classes) on the bit-parallel family vs the oracle;
-    k > 0 with wildcards is refused, not approximated."""
+    """-w / -W exact search (shift_and with IUPAC classes) on the bit-parallel family vs the oracle."""
     rng = np.random.default_rng(800 + seed)
     ents = synth.make_entries(rng, 3, int(rng.integers(500, 3000)), n_runs=5, repeats=(seed % 2 == 0))
     L = int(rng.integers(8, 14))
@@ -289,5 +288,50 @@ def test_iupac_wildcards_exact(seed):
         got = sat_amd.sorted_tuples(pm.find_all())
         pm.close()
         assert got == want and len(want) > 0, (seed, tn, len(want), len(got))
-    with pytest.raises(sat_amd.PmError):
-        sat_amd.PatternMatch(k=1, wildcards=True)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_iupac_wildcards_inexact(seed):
+    """-w / -W with k > 0: the engines pick_pattern_index chooses (exact_halves over shift_and for
+    k = 1, filter_bitvec for k = 2) and forced ones, edits and substitutions, raw and normalized
+    streams, vs the oracle (which tests/test_oracle_vs_ref.py pins to the reference); also the
+    caller's re-alignment (editdist_alignment with wildcard-equal cells)."""
+    rng = np.random.default_rng(950 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(500, 3000)), n_runs=5, repeats=(seed % 2 == 0))
+    L = int(rng.integers(14, 22))
+    pats = []
+    for p in synth.make_patterns(rng, ents, int(rng.integers(10, 60)), length=L, planted=0.9, indel_frac=0.3, extras=False):
+        p = list(p)
+        for _ in range(int(rng.integers(0, 3))):
+            p[int(rng.integers(0, len(p)))] = str(rng.choice(list("RYKMSWBDHVN")))
+        pats.append("".join(p))
+    table = synth.table_for(ents)
+    raw = np.frombuffer(synth.stream(ents), dtype=np.uint8)
+    codes = synth.normalize(synth.stream(ents), table)
+    total = 0
+    for stream_codes, tbl in ((codes, table), (raw, None)):
+        text = O.Text(stream_codes, tbl)
+        for tn in (False, True):
+            for k in (1, 2):
+                for indels in (True, False):
+                    for sem in (sat_amd.SEM_AUTO, sat_amd.SEM_FILTER_BITVEC, 14, sat_amd.SEM_SHIFT_AND_INEXACT):
+                        want = O.find_all(text, pats, engine=sem, k=k, indels=indels, wildcards=True, text_n=tn)
+                        pm = sat_amd.PatternMatch(k=k, indels=indels, wildcards=True, text_n=tn, semantics=sem)
+                        for i, p in enumerate(pats):
+                            pm.add_pattern(p, i + 1)
+                        pm.init(stream_codes, tbl)
+                        assert pm.selected()[1] == sat_amd.KERNEL_BITPAR
+                        hits = pm.find_all()
+                        got = sat_amd.sorted_tuples(hits)
+                        assert got == O.sorted_tuples(want), (seed, tbl is None, tn, k, indels, sem, len(got), len(want))
+                        total += len(got)
+                        if sem == sat_amd.SEM_AUTO and len(got):
+                            al = pm.align_hits(hits)
+                            for h, a in zip(hits[:50], al[:50]):
+                                rc, st, en, ed, val = O.cli_align(text, pats[int(h["pid"]) - 1], int(h["end"]), k, indels, wildcards=True, text_n=tn)
+                                if ed == 2**31 - 1:        # no alignment within k at this end ("Bogus hit"): only that verdict is defined
+                                    assert a["editdist"] == ed, (seed, h)
+                                else:
+                                    assert (a["start"], a["end"], a["editdist"], a["value"]) == (st, en, ed, val), (seed, h)
+                        pm.close()
+    assert total > 0

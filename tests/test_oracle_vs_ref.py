@@ -89,3 +89,42 @@ def test_fuzz_wildcards_against_reference(ref_harness, seed):
             ref = sorted(tuple(int(x) for x in l.split()) for l in out.stdout.splitlines() if not l.startswith("#"))
             got = O.sorted_tuples(O.find_all(text, pats, engine=4, k=0, wildcards=True, text_n=tn))
             assert got == ref, (seed, flag)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_wildcards_inexact_against_reference(ref_harness, seed):
+    """-w / -W with k > 0: wildcard-equal cells in editdist_alignment (pattern_alignment.cc:317-319,
+    461-475, 514-590) and global_align (primer_alignment.cc:151-154, 253-280); engines as
+    pick_pattern_index chooses them (exact_halves over shift_and for k = 1, filter_bitvec for k = 2)
+    and forced."""
+    import os, subprocess, tempfile
+    rng = np.random.default_rng(900 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(400, 2500)), n_runs=4, repeats=(seed % 2 == 0))
+    L = int(rng.integers(14, 22))
+    pats = []
+    for p in synth.make_patterns(rng, ents, int(rng.integers(8, 40)), length=L, planted=0.9, indel_frac=0.3, extras=False):
+        p = list(p)
+        for _ in range(int(rng.integers(0, 3))):
+            p[int(rng.integers(0, len(p)))] = str(rng.choice(list("RYKMSWBDHVN")))
+        pats.append("".join(p))
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    total = 0
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "db.sqn"), "wb").write(codes.tobytes())
+        open(os.path.join(d, "db.tbl"), "wb").write(table)
+        open(os.path.join(d, "pat.txt"), "w").write("\n".join(pats) + "\n")
+        for flag, tn in (("-w", False), ("-W", True)):
+            for k in (1, 2):
+                for indels in (True, False):
+                    for sel in (0, 5, 14, 100):
+                        cmd = [ref_harness, "-N", str(sel), flag, "-k" if indels else "-K", str(k), "-n", "-i", os.path.join(d, "db"),
+                               "-P", os.path.join(d, "pat.txt")]
+                        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                        assert out.returncode == 0, (cmd, out.stderr[-300:])
+                        ref = sorted(tuple(int(x) for x in l.split()) for l in out.stdout.splitlines() if not l.startswith("#"))
+                        got = O.sorted_tuples(O.find_all(text, pats, engine=sel, k=k, indels=indels, wildcards=True, text_n=tn))
+                        assert got == ref, (seed, flag, k, indels, sel, len(got), len(ref))
+                        total += len(ref)
+    assert total > 0
