@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <thread>
 #include <unordered_map>
 
 #include "pm_internal.h"
@@ -590,11 +591,27 @@ int fetch_windows(pm_handle *h, std::vector<Window> &wins) {
   h->winbuf.resize((size_t)total + 1);
   if (wins.empty()) return PM_OK;
   if (h->h_text) {
-    for (const Window &w : wins)
-      for (int i = 0; i < w.len; ++i) {
-        const int64_t p = w.start + i;
-        h->winbuf[w.off + i] = (p >= 0 && p < h->n) ? h->h_text[p] : 0;
+    // host copy of the stream: copy + code -> character in one pass, slices of windows per thread
+    auto copy = [&](size_t lo, size_t hi) {
+      for (size_t wi = lo; wi < hi; ++wi) {
+        const Window &w = wins[wi];
+        for (int i = 0; i < w.len; ++i) {
+          const int64_t p = w.start + i;
+          h->winbuf[w.off + i] = h->alpha.ch[(p >= 0 && p < h->n) ? h->h_text[p] : 0];
+        }
       }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = wins.size() < 4096 ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+    if (nthreads <= 1) copy(0, wins.size());
+    else {
+      std::vector<std::thread> pool;
+      const size_t per = (wins.size() + nthreads - 1) / nthreads;
+      for (size_t t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t]() { copy(std::min(wins.size(), t * per), std::min(wins.size(), (t + 1) * per)); });
+      for (std::thread &th : pool) th.join();
+    }
+    return PM_OK;
   } else {
     const size_t cnt = wins.size();
     if (h->d_wcap < cnt) {
@@ -1007,12 +1024,14 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
   if (k > 0 || wc_exact) { int rc = fetch_windows(h, wins); if (rc) return rc; }
   AlignParams prm; prm.k = k; prm.indels = h->cfg.indels != 0; prm.eos = (uint8_t)h->cfg.eos;
   prm.wc = h->cfg.wildcards != 0; prm.tn = h->cfg.text_n != 0;
-  for (size_t i = 0; i < n; ++i) {
+  // the hits are independent: worker threads take contiguous slices (own DP scratch each)
+  auto run = [&](size_t lo, size_t hi, AlignScratch &scratch) -> bool {
+  for (size_t i = lo; i < hi; ++i) {
     const int L = (int)pp[i]->s.size();
     if (wc_exact) {
       // start = end - L; per character: equal, IUPAC-compatible (text N only with -W), or substitution
       const int64_t st = hits[i].end - L;
-      if ((size_t)L + 1 > stride && ops) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
+      if ((size_t)L + 1 > stride && ops) return false;
       int subs = 0;
       for (int q = 0; q < L; ++q) {
         const int64_t tp = st + q;
@@ -1034,7 +1053,7 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
     if (k == 0) {                                                    // exact_alignment (pattern_alignment.cc:29-43)
       out[i].start = hits[i].end - L; out[i].end = hits[i].end; out[i].editdist = 0; out[i].value = 0;
       if (ops) {
-        if ((size_t)L + 1 > stride) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
+        if ((size_t)L + 1 > stride) return false;
         memset(ops + i * stride, '|', (size_t)L); ops[i * stride + L] = 0;
         memcpy(text + i * stride, pp[i]->s.data(), (size_t)L); text[i * stride + L] = 0;
       }
@@ -1042,16 +1061,32 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
     }
     std::string opstr;
     AlignResult r = editdist_align(h->winbuf.data() + wins[i].off, wins[i].start, hits[i].end, hits[i].end,
-                                   pp[i]->s.data(), L, pp[i]->esb, pp[i]->eeb, prm, h->scratch, ops ? &opstr : nullptr);
+                                   pp[i]->s.data(), L, pp[i]->esb, pp[i]->eeb, prm, scratch, ops ? &opstr : nullptr);
     out[i].start = r.start; out[i].end = r.end; out[i].editdist = r.editdist; out[i].value = r.value;
     if (ops) {
       const int64_t tl = r.end - r.start;                              // matching text (pattern_alignment.cc:603-606)
-      if (opstr.size() + 1 > stride || tl < 0 || (size_t)tl + 1 > stride) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
+      if (opstr.size() + 1 > stride || tl < 0 || (size_t)tl + 1 > stride) return false;
       memcpy(ops + i * stride, opstr.data(), opstr.size()); ops[i * stride + opstr.size()] = 0;
       for (int64_t q = 0; q < tl; ++q) text[i * stride + q] = (char)h->winbuf[wins[i].off + (r.start - wins[i].start) + q];
       text[i * stride + tl] = 0;
     }
   }
+  return true;
+  };
+  bool ok = true;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nthreads = n < 4096 ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+  if (nthreads <= 1) ok = run(0, n, h->scratch);
+  else {
+    std::vector<std::thread> pool;
+    std::vector<char> good(nthreads, 1);
+    const size_t per = (n + nthreads - 1) / nthreads;
+    for (size_t t = 0; t < nthreads; ++t)
+      pool.emplace_back([&, t]() { AlignScratch sc; good[t] = run(std::min(n, t * per), std::min(n, (t + 1) * per), sc) ? 1 : 0; });
+    for (std::thread &th : pool) th.join();
+    for (char g : good) ok = ok && g;
+  }
+  if (!ok) return fail(h, PM_E_INVALID, "pm_align_hits_text: stride too small");
   return PM_OK;
 }
 

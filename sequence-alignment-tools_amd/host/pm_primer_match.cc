@@ -402,9 +402,11 @@ int main(int argc, char **argv) {
     nhits += l.size();
     const int64_t oldcharspos = ff.pos();
     hv.resize(l.size()); al.resize(l.size());
-    opsbuf.assign(l.size() * stride, 0); textbuf.assign(l.size() * stride, 0);
+    if (opt.alignments) { opsbuf.assign(l.size() * stride, 0); textbuf.assign(l.size() * stride, 0); }
     for (size_t j = 0; j < l.size(); ++j) { hv[j].end = l[j].key; hv[j].pid = (uint32_t)l[j].id; hv[j].k = l[j].value; hv[j].aux[0] = hv[j].aux[1] = hv[j].aux[2] = 0; }
-    if (!l.empty() && pm_align_hits_text(kt.handle(), hv.data(), hv.size(), al.data(), opsbuf.data(), textbuf.data(), stride) != PM_OK) {
+    // counts only (-c): distances are enough, no alignment strings
+    if (!l.empty() && (opt.alignments ? pm_align_hits_text(kt.handle(), hv.data(), hv.size(), al.data(), opsbuf.data(), textbuf.data(), stride)
+                                      : pm_align_hits(kt.handle(), hv.data(), hv.size(), al.data())) != PM_OK) {
       fprintf(stderr, "Fatal error: alignment: %s\n", pm_last_error(kt.handle()));
       return 1;
     }
