@@ -13,7 +13,6 @@
 #include <unistd.h>
 
 #include <chrono>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,19 +62,6 @@ struct Options {
           "  -D (0|2|3)  -I  -B  -v  -h\n");
   exit(1);
 }
-
-// -v: wall-clock seconds per phase on stderr (the reference prints timestamp() lines there)
-struct Phases {
-  bool on = false;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
-  void mark(const char *what) {
-    if (!on) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[%8.3f s, +%7.3f] %s\n", std::chrono::duration<double>(now - t0).count(),
-            std::chrono::duration<double>(now - last).count(), what);
-    last = now;
-  }
-};
 
 int tilde(const char *a) { return a[0] == '~' ? -atoi(a + 1) : atoi(a); }
 

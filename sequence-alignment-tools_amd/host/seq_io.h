@@ -8,7 +8,9 @@
 // * FASTA / UniSTS pattern readers (reference fasta_io.cc:11-58, sts_io.cc:11-47).
 // * IUPAC reverse complement (reference util.cc:319-381).
 #pragma once
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <istream>
 #include <string>
 #include <vector>
@@ -65,5 +67,18 @@ struct StsEntry {                                     // sts_io.h:11-94
   unsigned long sizelb = 0, sizeub = 0;
 };
 void read_sts_entry(std::istream &is, StsEntry *e);   // sts_io.cc:11-47 (fields of a short line keep their old values)
+
+// -v of the command lines: wall-clock seconds per phase on stderr (the reference prints timestamp() lines there)
+struct Phases {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[%8.3f s, +%7.3f] %s\n", std::chrono::duration<double>(now - t0).count(),
+            std::chrono::duration<double>(now - last).count(), what);
+    last = now;
+  }
+};
 
 }  // namespace pmgpu
