@@ -340,7 +340,7 @@ __device__ __forceinline__ void verify_hit(const SeedArgs *ap, uint32_t mlo, uin
 // packed distance (2 bits per base) never exceeds the true one: a cheap necessary condition
 __device__ __forceinline__ bool packed_close(const uint2 &pp, uint64_t W, int k) {
   const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
-  return __popcll((x | (x >> 1)) & 0x5555555555555555ull) <= k;
+  return (int)__popcll((x | (x >> 1)) & 0x5555555555555555ull) <= k;
 }
 
 template <bool HALVES>
