@@ -160,6 +160,26 @@ def test_candidate_overflow_is_reported_and_recovered():
     pm.close()
 
 
+def test_halves_seed_overflow_is_recovered():
+    """exact_halves -k on the seed kernels reserves output slots 64 at a time: a buffer smaller
+    than the reservations must be reported (PM_E_OVERFLOW) and grown by pm_scan, same hits."""
+    c, codes, table, allp = load([p for p in CASES if "small_mixed" in p][0])
+    want = None
+    for cap in (1 << 20, 64, 1000):
+        pm = sat_amd.PatternMatch(k=1, indels=True, kernel=sat_amd.KERNEL_SEED)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        assert pm.selected() == (sat_amd.SEM_EXACT_HALVES, sat_amd.KERNEL_SEED)
+        pm.set_capacity(cap)
+        got = sat_amd.sorted_tuples(pm.find_all())
+        pm.close()
+        if want is None:
+            want = got
+        assert got == want and len(got) > 0, (cap, len(got), len(want))
+    assert want == [tuple(h) for h in c["engine"]["auto_k1"]["hits"]]
+
+
 def test_device_finalize_equals_host_finalize():
     """pm_finalize_device (hipCUB sort + segmented pass on the GPU) == the host stage, incl. clusters
     on tandem repeats and the deferral at the end of a partial range."""
