@@ -240,7 +240,8 @@ def main():
         pm.add_pattern(p, i + 1)
     t0 = time.time()
     pm.init_device(stream.data_ptr(), stream.numel(), TABLE, stream=torch.cuda.current_stream().cuda_stream, keepalive=stream)
-    pm.set_capacity(1 << 24)
+    # record buffer: the edit-distance seed plan reports a candidate through several seeds before its dedup
+    pm.set_capacity(1 << 28 if (args.indels and args.k >= 2) else 1 << 24)
     log("index build %.2f s; semantics=%s kernel=%s" % (time.time() - t0, *pm.selected()))
     begin, end = lo - glo, hi - glo
 

@@ -58,10 +58,12 @@ struct pm_handle {
   std::vector<SeedDevice> sd_more;    // further tiles when the pattern set is too large for one LDS filter
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
+  bool edits_dev = false;             // filter_bitvec / shift_and_inexact -k on the seed kernels: records deduplicated after the scan
   pm_hit *d_ext = nullptr;            // its output (swapped with d_cands after every scan)
   uint8_t *d_half_codes = nullptr, *d_half_len = nullptr;
   int32_t *d_hesb = nullptr, *d_heeb = nullptr;
   int scan_k = 0, seed_k = 0;
+  int64_t scan_end = 0;               // end of the range of the scan in flight / last scan
   bool scan_indels = false;
   pm_hit *d_cands = nullptr;
   unsigned long long *d_counter = nullptr;
@@ -268,6 +270,13 @@ static bool seed_eligible(pm_handle *h, std::string *why) {
     for (const Pattern &p : h->pats) if (p.s.size() > 32 || p.s.size() < 16) { *why = "exact_halves -k on the seed family needs 16..32 character patterns"; return false; }
     return true;
   }
+  if (h->cfg.k > 0 && h->cfg.indels && (sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_SHIFT_AND_INEXACT)) {
+    // the automaton's candidates from displaced-piece seeds + a per-seed automaton run (pm_seed.hip, EDITS)
+    if (h->cfg.k > 2) { *why = "edit distance > 2 runs on the bit-parallel family"; return false; }
+    for (const Pattern &p : h->pats) if (p.s.size() > 32 || p.s.size() < 20) { *why = "the edit-distance seed plan needs 20..32 character patterns"; return false; }
+    for (uint32_t id : h->inner_ids) if (id >= (1u << 22)) { *why = "the edit-distance seed plan packs pattern ids into 22 bits"; return false; }
+    return true;
+  }
   if (h->cfg.k > 0 && h->cfg.indels && sem != PM_SEM_KEYWORD_TREE && sem != PM_SEM_SHIFT_AND) { *why = "edit-distance search (-k) runs on the bit-parallel family"; return false; }
   if (sem == PM_SEM_EXACT_BASES) { *why = "exact_bases runs on the bit-parallel family"; return false; }
   if (sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_EXACT_HALVES)
@@ -302,6 +311,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     std::vector<std::string> partners;
     std::vector<uint8_t> sides;
     const bool halves_mode = h->sem == PM_SEM_EXACT_HALVES && h->cfg.indels && h->cfg.k > 0;
+    const bool edits_mode = h->cfg.indels && h->cfg.k > 0 && (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT);
     if (halves_mode) {                            // halves as exact patterns (ids 2j+1, 2j+2), partner = other half
       sp = h->inner; sid = h->inner_ids; sk = 0;
       for (size_t i = 0; i + 1 < sp.size(); i += 2) {
@@ -332,7 +342,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       if (halves_mode) { tpart.assign(partners.begin() + lo, partners.begin() + hi); tside.assign(sides.begin() + lo, sides.begin() + hi); }
       SeedTables st;
       why = seed_build(tp, tid, h->alpha, sk, h->eos_code, &st, force_lw, halves_mode ? &tpart : nullptr,
-                       halves_mode ? &tside : nullptr, h->cfg.k);
+                       halves_mode ? &tside : nullptr, h->cfg.k, edits_mode);
       if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < (halves_mode ? 8 : 10)) why = "patterns too short for the seed family";
       if (!why.empty()) break;
       SeedDevice *dst = &h->sd;
@@ -353,6 +363,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       h->kern = PM_KERNEL_SEED;
       h->seed_flags = h->sem == PM_SEM_EXACT_HALVES && !halves_mode;
       h->halves_dev = halves_mode;
+      h->edits_dev = edits_mode;
       if (halves_mode) {
         const size_t nh = h->inner.size();
         std::vector<uint8_t> codes(nh * 16, 0), lens(nh, 0);
@@ -378,7 +389,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     }
   }
   if (!want_seed) {
-    h->halves_dev = false;
+    h->halves_dev = false; h->edits_dev = false;
     h->kern = PM_KERNEL_BITPAR;
     BitparTables tabs;
     std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs,
@@ -391,6 +402,10 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
   if (!h->ev1) HIP_TRY(h, hipEventCreate(&h->ev1));
   if (!h->d_cands) { rc = ensure_capacity(h, (size_t)1 << 20); if (rc) return rc; }
+  if (h->edits_dev) {                                               // every candidate is reported by several seeds before the dedup
+    const size_t want = std::min<size_t>(std::max<size_t>((size_t)(h->n / 24), (size_t)1 << 22), (size_t)1 << 28);
+    if (h->cap < want) { rc = ensure_capacity(h, want); if (rc) return rc; }
+  }
   h->inited = true;
   return pm_reset(h);
 }
@@ -472,11 +487,70 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   }
   else
     HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
-  h->scan_begin = begin;
+  h->scan_begin = begin; h->scan_end = end;
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   if (h->kern != PM_KERNEL_SEED) h->last_launches = 1;
   h->scan_pending = true;
+  return PM_OK;
+}
+
+// sort workspace shared by pm_finalize_device (clustering) and the edit-distance dedup
+static int ensure_sort_workspace(pm_handle *h, size_t n, bool with_out) {
+  if (h->ckeys_cap < n || !h->d_keys) {
+    void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft};
+    for (void *q : fw) if (q) (void)hipFree(q);
+    h->d_keys = h->d_keys_alt = nullptr; h->d_ctemp = nullptr; h->d_fout = h->d_fleft = nullptr;
+    h->ckeys_cap = std::max<size_t>(n + n / 4, (size_t)1 << 16);
+    HIP_TRY(h, hipMalloc((void **)&h->d_keys, h->ckeys_cap * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_keys_alt, h->ckeys_cap * 8));
+    h->ctemp_bytes = cluster_temp_bytes(h->ckeys_cap);
+    HIP_TRY(h, hipMalloc(&h->d_ctemp, h->ctemp_bytes ? h->ctemp_bytes : 16));
+  }
+  if (with_out && !h->d_fout) {
+    HIP_TRY(h, hipMalloc((void **)&h->d_fout, h->ckeys_cap * sizeof(pm_hit)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_fleft, h->ckeys_cap * sizeof(pm_hit)));
+  }
+  if (!h->d_fcounts) {
+    HIP_TRY(h, hipMalloc((void **)&h->d_fcounts, 2 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipHostMalloc((void **)&h->h_fcounts, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  return PM_OK;
+}
+
+// Edit-distance seed plan: windows that do not fit in front of the stream start are not seeded, so
+// every candidate that ends in the first Lw+2k+2 characters is produced here by running the
+// automaton itself (shift_and_inexact.cc:249-352, rows start with l prefix bits :162-164) for each
+// pattern over those few characters; the kernel's records for the same ends are duplicates and
+// leave with the dedup.
+static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
+  const int k = h->cfg.k;
+  const int64_t T = std::min<int64_t>(std::min<int64_t>(h->n, h->scan_end), h->sd.Lw + 2 * k + 2);
+  if (T <= 0) return PM_OK;
+  uint8_t head[64] = {0};
+  if (h->h_text) memcpy(head, h->h_text, (size_t)T);
+  else HIP_TRY(h, hipMemcpy(head, h->d_text, (size_t)T, hipMemcpyDeviceToHost));
+  for (size_t j = 0; j < h->inner.size(); ++j) {
+    const std::string &s = h->inner[j].s;
+    const int L = (int)s.size();
+    uint64_t R[3] = {0, 1, 3};
+    const uint64_t last = 1ull << (L - 1);
+    for (int64_t t = 0; t < T; ++t) {
+      const int c = head[t];
+      if (c == h->eos_code) { R[0] = R[1] = R[2] = 0; continue; }
+      uint64_t U = 0;
+      for (int i = 0; i < L; ++i) if (h->alpha.nch[(unsigned char)s[i]] == c) U |= 1ull << i;
+      const uint64_t x0 = (R[0] << 1) | 1, m1 = x0 | R[0], n0 = x0 & U;
+      const uint64_t x1 = (R[1] << 1) | 1, n1 = (x1 & U) | m1 | (n0 << 1) | 1 | n0, m2 = x1 | R[1];
+      const uint64_t x2 = (R[2] << 1) | 1, n2 = (x2 & U) | m2 | (n1 << 1) | 1 | n1;
+      R[0] = n0; R[1] = n1; R[2] = n2;
+      const int lvl = (R[0] & last) ? 0 : (R[1] & last) ? 1 : (k >= 2 && (R[2] & last)) ? 2 : -1;
+      if (lvl >= 0 && t + 1 > h->scan_begin) {
+        pm_hit x; x.end = t + 1; x.pid = h->inner_ids[j]; x.k = (uint8_t)lvl; x.aux[0] = x.aux[1] = x.aux[2] = 0;
+        extra->push_back(x);
+      }
+    }
+  }
   return PM_OK;
 }
 
@@ -539,6 +613,28 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     h->last_count = (size_t)*h->h_counter;
     if (n_out) *n_out = h->last_count;
     h->last_launches += 1;
+  }
+  if (h->edits_dev) {
+    // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
+    size_t tot = cnt;
+    if (h->scan_begin == 0) {
+      std::vector<pm_hit> extra;
+      int rc = edits_start_candidates(h, &extra);
+      if (rc) return rc;
+      if (tot + extra.size() > h->cap) { h->last_count = 0; if (n_out) *n_out = tot + extra.size(); return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
+      if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
+      tot += extra.size();
+    }
+    int rc = ensure_sort_workspace(h, tot, false);
+    if (rc) return rc;
+    HIP_TRY(h, dedup_device(h->d_cands, tot, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes, h->d_cands, h->d_fcounts, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->last_count = (size_t)h->h_fcounts[0];
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] edits: %zu raw records (with holes) -> %zu unique candidates\n", tot, h->last_count);
+    if (n_out) *n_out = h->last_count;
+    h->last_launches += 3;
+    return PM_OK;
   }
   if (h->kern == PM_KERNEL_SEED && h->scan_begin == 0 && h->seed_k > 0 &&
       (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT)) {
@@ -723,13 +819,28 @@ int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
   if (rc) return rc;
   AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
   prm.wc = h->cfg.wildcards != 0; prm.tn = h->cfg.text_n != 0;
-  for (size_t wi = 0; wi < need_dp.size(); ++wi) {
-    const Cluster &c = need_dp[wi];
-    const Pattern &p = h->pats[c.pid - 1];
-    AlignResult r = editdist_align(h->winbuf.data() + wins[wi].off, wins[wi].start, c.first, c.last,
-                                   p.s.data(), (int)p.s.size(), p.esb, p.eeb, prm, h->scratch);
-    if (r.ok) outv.push_back(make_hit(r.end, p.id, r.value));       // :135
+  // one DP per cluster; the clusters are independent: slices per host thread, results kept in order
+  std::vector<AlignResult> res(need_dp.size());
+  auto run = [&](size_t lo, size_t hi, AlignScratch &scratch) {
+    for (size_t wi = lo; wi < hi; ++wi) {
+      const Cluster &c = need_dp[wi];
+      const Pattern &p = h->pats[c.pid - 1];
+      res[wi] = editdist_align(h->winbuf.data() + wins[wi].off, wins[wi].start, c.first, c.last,
+                               p.s.data(), (int)p.s.size(), p.esb, p.eeb, prm, scratch);
+    }
+  };
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nthreads = need_dp.size() < 4096 ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+  if (nthreads <= 1) run(0, need_dp.size(), h->scratch);
+  else {
+    std::vector<std::thread> pool;
+    const size_t per = (need_dp.size() + nthreads - 1) / nthreads;
+    for (size_t t = 0; t < nthreads; ++t)
+      pool.emplace_back([&, t]() { AlignScratch sc; run(std::min(need_dp.size(), t * per), std::min(need_dp.size(), (t + 1) * per), sc); });
+    for (std::thread &th : pool) th.join();
   }
+  for (size_t wi = 0; wi < need_dp.size(); ++wi)
+    if (res[wi].ok) outv.push_back(make_hit(res[wi].end, h->pats[need_dp[wi].pid - 1].id, res[wi].value));   // :135
   return PM_OK;
 }
 
@@ -939,21 +1050,8 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
     if (n_out) *n_out = n;
     return PM_OK;
   }
-  // workspace
-  if (h->ckeys_cap < n || !h->d_keys) {
-    void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft};
-    for (void *q : fw) if (q) (void)hipFree(q);
-    h->ckeys_cap = std::max<size_t>(n + n / 4, (size_t)1 << 16);
-    HIP_TRY(h, hipMalloc((void **)&h->d_keys, h->ckeys_cap * 8));
-    HIP_TRY(h, hipMalloc((void **)&h->d_keys_alt, h->ckeys_cap * 8));
-    h->ctemp_bytes = cluster_temp_bytes(h->ckeys_cap);
-    HIP_TRY(h, hipMalloc(&h->d_ctemp, h->ctemp_bytes ? h->ctemp_bytes : 16));
-    HIP_TRY(h, hipMalloc((void **)&h->d_fout, h->ckeys_cap * sizeof(pm_hit)));
-    HIP_TRY(h, hipMalloc((void **)&h->d_fleft, h->ckeys_cap * sizeof(pm_hit)));
-  }
-  if (!h->d_fcounts) {
-    HIP_TRY(h, hipMalloc((void **)&h->d_fcounts, 2 * sizeof(unsigned long long)));
-    HIP_TRY(h, hipHostMalloc((void **)&h->h_fcounts, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  { int rcw = ensure_sort_workspace(h, n, true); if (rcw) return rcw; }
+  if (!h->d_fpat_len) {
     std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
     for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
     HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));

@@ -69,7 +69,58 @@ __global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64
   }
 }
 
+// ---- duplicate removal for the edit-distance seed plan --------------------------------------------
+// Several seeds (combos, displacement patterns) lead to the same (pattern, end) candidate and the
+// records come in blocks with unused slots: pack (holes get the largest key), sort, keep the first
+// of every run of equal keys.
+constexpr uint64_t DEDUP_HOLE = ~0ull;
+
+__global__ void pm_dedup_pack(const pm_hit *in, size_t n, uint64_t *keys) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pm_hit h = in[i];
+  keys[i] = h.pid == PM_SEED_HOLE ? DEDUP_HOLE
+                                  : ((uint64_t)h.pid << 42) | (((uint64_t)h.end & 0xffffffffffull) << 2) | (uint64_t)(h.k & 3u);
+}
+
+// keys sorted: equal (pattern, end) are adjacent and the smallest level comes first
+__global__ void pm_dedup_unpack(const uint64_t *keys, size_t n, pm_hit *out, unsigned long long *count) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  bool head = false;
+  uint64_t key = 0;
+  if (i < n) {
+    key = keys[i];
+    head = key != DEDUP_HOLE && (i == 0 || (keys[i - 1] >> 2) != (key >> 2));
+  }
+  const unsigned long long bal = __ballot(head);
+  if (bal == 0) return;
+  const int lane = threadIdx.x & 63;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(bal));
+  base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+  if (head) {
+    pm_hit h;
+    h.pid = (uint32_t)(key >> 42); h.end = (int64_t)((key >> 2) & 0xffffffffffull); h.k = (uint8_t)(key & 3u);
+    h.aux[0] = h.aux[1] = h.aux[2] = 0;
+    out[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))] = h;
+  }
+}
+
 }  // namespace
+
+// d_out may alias d_in (the keys are a copy).  *d_count receives the number of unique records.
+hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                        pm_hit *d_out, unsigned long long *d_count, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess || n == 0) return e;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((n + threads - 1) / threads);
+  hipLaunchKernelGGL(pm_dedup_pack, dim3(blocks), dim3(threads), 0, st, d_in, n, d_keys);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(pm_dedup_unpack, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, d_out, d_count);
+  return hipGetLastError();
+}
 
 size_t cluster_temp_bytes(size_t n) {
   size_t bytes = 0;

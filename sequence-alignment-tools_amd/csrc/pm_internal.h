@@ -89,6 +89,10 @@ hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_t
 constexpr uint32_t PM_SEED_HOLE = 0xffffffffu;   // pid of an unused slot in the half-seed record buffer
 constexpr int SEED_OUT_BLOCK = 64;               // slots a wave reserves per atomic (exact_halves -k seeds)
 
+// duplicate and hole removal for the edit-distance seed plan (pm_cluster.hip); d_out may alias d_in
+hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                        pm_hit *d_out, unsigned long long *d_count, hipStream_t st);
+
 // ---- seed extension DP on the GPU (pm_extend.hip) ---------------------------------------------
 hipError_t extend_seeds(const uint8_t *d_text, int64_t n, const pm_hit *d_seeds, size_t nseeds,
                         const uint8_t *d_half_codes, const uint8_t *d_half_len, const int32_t *d_esb, const int32_t *d_eeb,

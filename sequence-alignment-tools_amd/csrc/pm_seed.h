@@ -34,6 +34,7 @@ struct SeedTables {
   std::vector<uint8_t> pat_codes;                 // 32 bytes per pattern
   bool halves = false; int hk = 0;                // exact_halves -k mode: partner half per pattern
   int hfast = 0;                                  // see SeedArgs::hfast
+  int edits = 0;                                  // > 0: edit-distance seed plan for this k (records in pat_codes)
   int eos_code = -1;
   std::vector<uint32_t> part32;
   std::vector<uint8_t> part_len, part_side;
@@ -46,7 +47,8 @@ struct SeedDevice {
   void *pat40 = nullptr, *d_args = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr;
   uint32_t *part32 = nullptr;
-  bool halves = false; int hk = 0, hfast = 0, eos_code = -1;
+  bool halves = false; int hk = 0, hfast = 0, eos_code = -1, edits = 0;
+  uint32_t emask_a[SEED_MAX_COMBOS] = {}, emask_b[SEED_MAX_COMBOS] = {};
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
   int mode = 0;
   int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;
@@ -58,7 +60,7 @@ struct SeedDevice {
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
                        const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin = 0,
                        const std::vector<std::string> *partners = nullptr, const std::vector<uint8_t> *sides = nullptr,
-                       int halves_k = 0);
+                       int halves_k = 0, bool edits = false);
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
 void seed_free(SeedDevice *d);
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);

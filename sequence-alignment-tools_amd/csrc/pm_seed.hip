@@ -47,7 +47,7 @@ struct SeedArgs {
   int64_t chunk0;                       // first chunk index (absolute, chunk_len aligned)
   int64_t chunk_len;                    // bytes per workgroup, multiple of 1024*WAVES
   int nchunks, ncombos, group;          // group = chunks per (superchunk, combo) run
-  int k, Lw, pb, r, ascii, debug;
+  int k, Lw, pb, r, ascii, debug, maxlen;
   uint32_t mask_lo[SEED_MAX_COMBOS];    // window bits (2 per base) that belong to the combo's pieces
   uint32_t mask_hi[SEED_MAX_COMBOS];
   uint32_t perm_sel[SEED_MAX_COMBOS];   // byte-aligned plans (pb == 4): v_perm selector gathering the pieces
@@ -66,6 +66,8 @@ struct SeedArgs {
   unsigned long long cap;
   int eos_code;                         // stream code of the end-of-sequence character, -1 = none
   int halves, hk;                       // exact_halves -k: patterns are halves, partner prefilter for hk edits
+  int edits;                            // > 0: filter_bitvec / shift_and_inexact with indels; pat_codes holds 32-byte automaton records
+  uint32_t emask_a[SEED_MAX_COMBOS], emask_b[SEED_MAX_COMBOS];   // byte masks (low window word) of the combo's first and second piece
   int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
                                         // partner's stream window is known before the half's record is read
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
@@ -337,6 +339,94 @@ __device__ __forceinline__ void verify_hit(const SeedArgs *ap, uint32_t mlo, uin
   if (HALVES) verify_half(ap, p, pi); else verify_exact(ap, mlo, mhi, p, pi);
 }
 
+// ---- edits (-k with filter_bitvec / shift_and_inexact semantics) --------------------------------
+// The candidates of these engines are the end positions at which the Wu-Manber k-error automaton
+// (shift_and_inexact.cc:249-352) has the pattern's last bit set.  A seed (3 clean pieces under one
+// of the displacement patterns) says "pattern pi ends within +-k of p+1"; the automaton is then
+// run for that one pattern over the L+k+4 stream characters in front of p+3, from the empty state
+// (its last bit depends on the last L+k characters only), and the ends p-1..p+3 are read off.
+// Record (seed_build): masks of A,C,G,T over the pattern positions (bit i = character i) | L | id.
+// Returns one nibble per end p-1+d, d = 0..4: level+1, or 0.
+__device__ __forceinline__ uint32_t edits_verify(const SeedArgs &a, int64_t p, uint32_t pi, uint32_t *pid) {
+  const uint4 *rec = reinterpret_cast<const uint4 *>(a.pat_codes + (size_t)pi * 32);
+  const uint4 M = rec[0], r = rec[1];
+  const int L = (int)(r.x & 0xffu), k = a.edits;
+  *pid = r.y;
+  const int64_t tend = p + 3 < a.n ? p + 3 : a.n;                 // characters [t0, tend) are consumed
+  int64_t t0 = p - 1 - L - k;
+  uint32_t R0 = 0, R1 = 0, R2 = 0;
+  if (t0 <= 0) { t0 = 0; R1 = 1u; R2 = 3u; }                      // true start of the stream: l prefix bits in row l (:162-164)
+  const uint32_t last = 1u << (L - 1);
+  const int nch = (a.maxlen + k + 4 + 15) >> 4;                   // wave-uniform number of 16-byte pieces
+  const int64_t base = p + 3 - 16 * (int64_t)nch;
+  uint32_t res = 0;
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    const int64_t off = base + 16 * c;
+    uint4 v;
+    if (off >= 0 && off + 16 <= a.n) __builtin_memcpy(&v, a.text + off, 16);
+    else {
+      uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const int64_t q = off + b;
+        const uint32_t x = (q >= 0 && q < a.n) ? (uint32_t)a.text[q] << (8 * (b & 3)) : 0u;
+        if (b < 4) w[0] |= x; else if (b < 8) w[1] |= x; else if (b < 12) w[2] |= x; else w[3] |= x;
+      }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int64_t t = off + b;
+      const bool live = t >= t0 && t < tend;
+      const uint32_t ch = (vw[b >> 2] >> (8 * (b & 3))) & 0xffu;
+      uint32_t U;
+      if (a.ascii) U = ch == 'A' ? M.x : ch == 'C' ? M.y : ch == 'G' ? M.z : ch == 'T' ? M.w : 0u;
+      else U = ch == 0 ? M.x : ch == 1 ? M.y : ch == 2 ? M.z : ch == 3 ? M.w : 0u;
+      const bool eos = (int)ch == a.eos_code;
+      // one character (pm_bitpar.hip step<K, true>): substitution, insertion and deletion terms
+      const uint32_t x0 = (R0 << 1) | 1u, m1 = x0 | R0;
+      const uint32_t n0 = x0 & U;
+      const uint32_t x1 = (R1 << 1) | 1u;
+      const uint32_t n1 = (x1 & U) | m1 | (n0 << 1) | 1u | n0;
+      const uint32_t m2 = x1 | R1;
+      const uint32_t x2 = (R2 << 1) | 1u;
+      const uint32_t n2 = (x2 & U) | m2 | (n1 << 1) | 1u | n1;
+      if (live) { R0 = eos ? 0u : n0; R1 = eos ? 0u : n1; R2 = eos ? 0u : n2; }
+      // ends p-1 .. p+3 are the positions after the characters p-2 .. p+2
+      const int d = (int)(t - (p - 2));
+      if (live && d >= 0 && d <= 4) {
+        const uint32_t lvl = (R0 & last) ? 1u : (R1 & last) ? 2u : (k >= 2 && (R2 & last)) ? 3u : 0u;
+        res |= lvl << (4 * d);
+      }
+    }
+  }
+  return res;
+}
+
+__device__ __forceinline__ pm_hit edit_record(int64_t end, uint32_t pid, uint32_t lvl1) {
+  pm_hit hh;
+  hh.end = end; hh.pid = pid; hh.k = (uint8_t)(lvl1 - 1u);
+  hh.aux[0] = hh.aux[1] = hh.aux[2] = 0;
+  return hh;
+}
+
+// rare paths (second match in a bucket, probe continuation): one atomic per record
+__device__ __noinline__ void verify_edits(const SeedArgs *ap, int64_t p, uint32_t pi) {
+  const SeedArgs &a = *ap;
+  uint32_t pid = 0;
+  const uint32_t res = edits_verify(a, p, pi, &pid);
+  for (int d = 0; d < 5; ++d) {
+    const uint32_t lvl1 = (res >> (4 * d)) & 15u;
+    const int64_t e = p - 1 + d;
+    if (lvl1 && e > a.begin && e <= a.end) {
+      const unsigned long long o = atomicAdd(a.counter, 1ull);
+      if (o < a.cap) a.out[o] = edit_record(e, pid, lvl1);
+    }
+  }
+}
+
 // packed distance (2 bits per base) never exceeds the true one: a cheap necessary condition
 __device__ __forceinline__ bool packed_close(const uint2 &pp, uint64_t W, int k) {
   const uint64_t x = W ^ (((uint64_t)pp.y << 32) | pp.x);
@@ -365,20 +455,23 @@ __device__ __forceinline__ uint32_t match_mask(const uint4 &q0, const uint4 &q1,
 // Second stage.  A 32-byte bucket (two 16-byte loads issued together) holds 8 fingerprinted
 // slots; the probe sequence ends at the first bucket with a free slot, which is almost always the
 // first one.  check_bucket tests the slots of a bucket that is already in registers.
-template <bool HALVES>
+template <bool HALVES, bool EDITS = false>
 __device__ __forceinline__ bool check_bucket(const SeedArgs &a, const uint4 &q0, const uint4 &q1, uint32_t fp, uint32_t imask,
                                              uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
   const uint32_t sl[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (sl[i] == EMPTY) return true;
-    if ((sl[i] & ~imask) == fp) verify_pattern<HALVES>(a, mlo, mhi, W, p, sl[i] & imask);
+    if ((sl[i] & ~imask) == fp) {
+      if (EDITS) verify_edits(a.self, p, sl[i] & imask);
+      else verify_pattern<HALVES>(a, mlo, mhi, W, p, sl[i] & imask);
+    }
   }
   return false;
 }
 
 // continue a probe sequence from bucket b (rare: only after a full bucket)
-template <bool HALVES>
+template <bool HALVES, bool EDITS = false>
 __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets, uint32_t b, uint32_t fp, uint32_t imask,
                                         uint32_t mlo, uint32_t mhi, uint64_t W, int64_t p) {
   const SeedArgs &a = *ap;
@@ -386,7 +479,7 @@ __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets
   for (;;) {
     b &= bmask;
     const uint4 q0 = buckets[2 * (size_t)b], q1 = buckets[2 * (size_t)b + 1];
-    if (check_bucket<HALVES>(a, q0, q1, fp, imask, mlo, mhi, W, p)) break;
+    if (check_bucket<HALVES, EDITS>(a, q0, q1, fp, imask, mlo, mhi, W, p)) break;
     ++b;
   }
 }
@@ -394,7 +487,7 @@ __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets
 
 // LW > 0: window length known at compile time (all shifts immediate); LW == 0: taken from a.Lw.
 // MODE: see window_hash.
-template <int LW, int MODE, bool HALVES>
+template <int LW, int MODE, bool HALVES, bool EDITS = false>
 __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   uint32_t *bloom = lds;                                          // SEED_BLOOM_WORDS dwords
@@ -429,9 +522,12 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   uint2 *queue = queue_all + wave * QCAP;
   const int64_t sub = a.chunk_len / WAVES;
   const int64_t ws = (a.chunk0 + cj) * a.chunk_len + (int64_t)wave * sub;   // first base of this wave
-  int64_t own_lo = ws > a.begin ? ws : a.begin;                   // p = index of the window's last base
+  // p = index of the window's last base.  EDITS: a candidate end e comes from seeds at p = e-1+-k, so the
+  // positions k beyond either side of (begin, end] are scanned too; records are filtered by e.
+  const int64_t p_lo = EDITS ? a.begin - a.edits : a.begin, p_hi = EDITS ? a.end + a.edits : a.end;
+  int64_t own_lo = ws > p_lo ? ws : p_lo;
   int64_t own_hi = ws + sub;
-  if (own_hi > a.end) own_hi = a.end;
+  if (own_hi > p_hi) own_hi = p_hi;
   if (own_hi > a.n) own_hi = a.n;
   const int Lw = LW > 0 ? LW : a.Lw;
   if (own_lo < Lw - 1) own_lo = Lw - 1;                           // the window must fit in the stream
@@ -494,6 +590,24 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     }
     ob_next += c; ob_left -= c;
   };
+  auto emit_edit = [&](bool pass, int64_t e, uint32_t pid, uint32_t lvl1) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(pass);
+    if (bal == 0) return;
+    const int c = __popcll(bal);
+    if (c > ob_left) {
+      if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+      ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)base);
+      ob_left = SEED_OUT_BLOCK;
+    }
+    if (pass) {
+      const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+      if (slot < a.cap) a.out[slot] = edit_record(e, pid, lvl1);
+    }
+    ob_next += c; ob_left -= c;
+  };
   auto process_q2 = [&]() __attribute__((always_inline)) {
     if (a.debug & 2) { q2n = 0; return; }
     for (int base = 0; base < q2n; base += 64) {
@@ -519,7 +633,17 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
         pidx = slot & imask;
-        if (!HALVES) pp = a.pat40[pidx];                             // halves: the record compare decides
+        if (!HALVES && !EDITS) pp = a.pat40[pidx];                   // halves / edits: their own record decides
+      }
+      if (EDITS) {                                                 // wave-uniform: automaton verify, block-reserved output
+        uint32_t pid = 0, res = 0;
+        if ((mm & 255u) && !(a.debug & 4)) res = edits_verify(a, p, pidx, &pid);
+#pragma unroll 1
+        for (int d = 0; d < 5; ++d) {
+          const uint32_t lvl1 = (res >> (4 * d)) & 15u;
+          const int64_t e = p - 1 + d;
+          emit_edit(lvl1 != 0 && e > a.begin && e <= a.end, e, pid, lvl1);
+        }
       }
       if (HALVES) {                                                // wave-uniform: block-reserved output
         uint32_t pid = 0;
@@ -550,7 +674,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       if ((mm & 511u) && !(a.debug & 4)) {
         const uint64_t W = ((uint64_t)whi << 32) | wlo;
         if (mm & 255u) {
-          if (!HALVES && packed_close(pp, W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pidx);
+          if (!HALVES && !EDITS && packed_close(pp, W, a.k)) verify_hit<HALVES>(a.self, mlo, mhi, p, pidx);
           uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);         // matches beyond the first (rare)
           while (rest) {
             const int sidx = __ffs(rest) - 1;
@@ -558,10 +682,11 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
             uint32_t slot = 0;
 #pragma unroll
             for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
-            verify_pattern<HALVES>(a, mlo, mhi, W, p, slot & imask);
+            if (EDITS) verify_edits(a.self, p, slot & imask);
+            else verify_pattern<HALVES>(a, mlo, mhi, W, p, slot & imask);
           }
         }
-        if (mm & 256u) probe_from<HALVES>(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
+        if (mm & 256u) probe_from<HALVES, EDITS>(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, W, p);
       }
     }
     q2n = 0;
@@ -626,46 +751,87 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
       own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
     }
-    // first stage, part 1: 16 hashes, 16 LDS reads in flight
-    uint32_t hs[16], wd[16];
+    // 32 window bits at base offset d from window i's first base (EDITS: displaced pieces; they only
+    // ever come from the low word, the last piece is never displaced)
+    auto wlo_at = [&](int i, int d) __attribute__((always_inline)) -> uint32_t {
+      const int s = 2 * (i - Lw + 33) + 2 * d;                     // 22 .. 60
+      return s < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, s) : __builtin_amdgcn_alignbit(cur, prev1, s - 32);
+    };
+    const uint32_t ema = EDITS ? a.emask_a[combo] : 0u, emb = EDITS ? a.emask_b[combo] : 0u;
+    // first stage, parts 1 and 2 for one displacement pattern (sa, sb = displacement of the combo's
+    // first and second piece; compile-time constants at every call): 16 hashes, 16 LDS reads in
+    // flight, three bit tests per window, verdicts funnelled into one register
+    auto tests = [&](int sa, int sb) __attribute__((always_inline)) -> uint32_t {
+      uint32_t hs[16], wd[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      uint32_t wlo, whi;
-      window(i, prev2, prev1, cur, wlo, whi);
-      uint32_t ss;
-      const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
-      hs[i] = bloom_selectors(ss);
-      wd[i] = bloom[h >> 17];                                      // word index = the 15 best-mixed bits
-    }
-    // part 2: three bit tests per window; the verdicts are funnelled into one register
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_alignbit(bloom_test(wd[i], hs[i]), acc, 1);
-    uint32_t rem = (acc >> 16) & own;
-    // part 3: compaction, one survivor per lane and round (ballot + mbcnt give the queue slots)
-    for (;;) {
-      const unsigned long long bal = __ballot(rem != 0);
-      if (bal == 0) break;
-      if (qn + 64 > QCAP) drain();
-      if (rem != 0) {
-        const int i = __ffs(rem) - 1;
-        __builtin_assume(i >= 0 && i < 16);
-        rem &= rem - 1;
-        const int sft = 2 * (i - Lw + 33);                         // per-lane bit offset of the window
-        const uint32_t x0 = __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = __builtin_amdgcn_alignbit(cur, prev1, sft),
-                       x2 = cur >> (sft & 31);
-        const uint32_t wlo = sft < 32 ? x0 : (sft < 64 ? x1 : x2);
-        const uint32_t whi = sft < 32 ? x1 : (sft < 64 ? x2 : 0u);
-        const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-        queue[slot] = make_uint2(wlo, (whi & 0xffu) | ((uint32_t)(pbase + i - ws) << 8));
+      for (int i = 0; i < 16; ++i) {
+        uint32_t wlo, whi;
+        window(i, prev2, prev1, cur, wlo, whi);
+        if (EDITS && (sa != 0 || sb != 0)) {
+          const uint32_t wb = sb ? wlo_at(i, sb) : wlo, wa = sa ? wlo_at(i, sa) : wlo;
+          wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
+        }
+        uint32_t ss;
+        const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
+        hs[i] = bloom_selectors(ss);
+        wd[i] = bloom[h >> 17];                                    // word index = the 15 best-mixed bits
       }
-      qn += __popcll(bal);
+      uint32_t acc = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_alignbit(bloom_test(wd[i], hs[i]), acc, 1);
+      return (acc >> 16) & own;
+    };
+    // EDITS: the displacement patterns (d1 between third and second piece, d2 between second and
+    // first), |d1|+|d2| <= k; survivors of all of them first, then one compaction loop
+    constexpr int NV = EDITS ? 13 : 1;
+    constexpr int VD1[13] = {0, 0, 0, 1, -1, 0, 0, 2, -2, 1, 1, -1, -1};
+    constexpr int VD2[13] = {0, 1, -1, 0, 0, 2, -2, 0, 0, 1, -1, 1, -1};
+    uint32_t rems[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int cost = (VD1[v] < 0 ? -VD1[v] : VD1[v]) + (VD2[v] < 0 ? -VD2[v] : VD2[v]);
+      rems[v] = 0;
+      if (!EDITS || cost <= a.edits) rems[v] = tests(VD1[v] + VD2[v], VD1[v]);
+    }
+    // part 3: compaction, one survivor per lane and round (ballot + mbcnt give the queue slots)
+#pragma unroll 1
+    for (int v = 0; v < NV; ++v) {
+      uint32_t rem = rems[0];
+      int sa = 0, sb = 0;
+      if (EDITS) {
+#pragma unroll
+        for (int t = 1; t < NV; ++t) if (v == t) { rem = rems[t]; sa = VD1[t] + VD2[t]; sb = VD1[t]; }
+      }
+      for (;;) {
+        const unsigned long long bal = __ballot(rem != 0);
+        if (bal == 0) break;
+        if (qn + 64 > QCAP) drain();
+        if (rem != 0) {
+          const int i = __ffs(rem) - 1;
+          __builtin_assume(i >= 0 && i < 16);
+          rem &= rem - 1;
+          const int sft = 2 * (i - Lw + 33);                       // per-lane bit offset of the window
+          const uint32_t x0 = __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = __builtin_amdgcn_alignbit(cur, prev1, sft),
+                         x2 = cur >> (sft & 31);
+          uint32_t wlo = sft < 32 ? x0 : (sft < 64 ? x1 : x2);
+          const uint32_t whi = sft < 32 ? x1 : (sft < 64 ? x2 : 0u);
+          if (EDITS && (sa | sb)) {                                // wave-uniform
+            const int fa = sft + 2 * sa, fb = sft + 2 * sb;
+            const uint32_t wa = fa < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, fa) : __builtin_amdgcn_alignbit(cur, prev1, fa);
+            const uint32_t wb = fb < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, fb) : __builtin_amdgcn_alignbit(cur, prev1, fb);
+            wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
+          }
+          const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+          queue[slot] = make_uint2(wlo, (whi & 0xffu) | ((uint32_t)(pbase + i - ws) << 8));
+        }
+        qn += __popcll(bal);
+      }
     }
   }
   drain();
   finish();
   process_q2();
-  if (HALVES && lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+  if ((HALVES || EDITS) && lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
 }
 
 }  // namespace
@@ -680,7 +846,7 @@ static uint64_t binom(int n, int r) {
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
                        const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin,
-                       const std::vector<std::string> *partners, const std::vector<uint8_t> *sides, int halves_k) {
+                       const std::vector<std::string> *partners, const std::vector<uint8_t> *sides, int halves_k, bool edits) {
   SeedTables &t = *out;
   t = SeedTables();
   t.k = k;
@@ -726,6 +892,8 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
     }
     if (best > 1e299) return "patterns too short for a k-mismatch seed plan";
   }
+  t.edits = edits ? k : 0;
+  if (edits && (t.mode != 1 || k < 1 || k > 2)) return "the edit-distance seed plan needs 20..32 character patterns and k = 1 or 2";
   const int m = k + t.r;
   // enumerate combos (r-subsets of m pieces) in lexicographic order
   std::vector<int> c(t.r);
@@ -795,6 +963,13 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
     t.pat_len[j] = (uint8_t)L;
     t.pat_id[j] = ids[j];
     for (int i = 0; i < L; ++i) t.pat_codes[j * 32 + i] = (uint8_t)alpha.nch[(unsigned char)s[i]];
+    if (edits) {                                   // the row becomes the automaton record edits_verify reads
+      uint32_t M[4] = {0, 0, 0, 0};
+      for (int i = 0; i < L; ++i) M[base2((unsigned char)s[i]) ^ (t.ascii && base2((unsigned char)s[i]) >= 2 ? 1 : 0)] |= 1u << i;   // A,C,G,T order
+      uint8_t *rec = &t.pat_codes[j * 32];
+      const uint32_t len = (uint32_t)L, idv = ids[j];
+      memcpy(rec, M, 16); memcpy(rec + 16, &len, 4); memcpy(rec + 20, &idv, 4); memset(rec + 24, 0, 8);
+    }
     if (partners) {                                // halves: the row doubles as the 32-byte record verify_half reads
       if (L > 16) return "exact_halves half longer than 16 characters";
       uint8_t *rec = &t.pat_codes[j * 32];
@@ -863,11 +1038,17 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part_len.data(), t.part_len.size(), (void **)&d->part_len)) != hipSuccess) return e;
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
   d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code;
+  d->edits = t.edits;
+  for (int c = 0; c < d->ncombos; ++c) {              // byte masks of the combo's first and second piece (edits: displaced pieces)
+    d->emask_a[c] = t.r >= 3 && t.combos[c][0] < 4 ? 0xffu << (8 * t.combos[c][0]) : 0u;
+    d->emask_b[c] = t.r >= 3 && t.combos[c][1] < 4 ? 0xffu << (8 * t.combos[c][1]) : 0u;
+  }
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
                            reinterpret_cast<const void *>(pm_seed_scan<20, 0, false>), reinterpret_cast<const void *>(pm_seed_scan<0, 0, false>),
-                           reinterpret_cast<const void *>(pm_seed_scan<0, 0, true>)};
+                           reinterpret_cast<const void *>(pm_seed_scan<0, 0, true>),
+                           reinterpret_cast<const void *>(pm_seed_scan<20, 1, false, true>)};
   for (const void *kf : kernels)
     if ((e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, SEED_LDS_BYTES)) != hipSuccess) return e;
   return hipStreamSynchronize(st);
@@ -887,6 +1068,7 @@ ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end) {
     if (v >= 1024 * WAVES) chunk = v / (1024 * WAVES) * (1024 * WAVES);
   }
   g.seg_len = chunk;
+  if (d.edits) { begin = begin > d.edits ? begin - d.edits : 0; end += d.edits; }   // seeds up to k positions outside (begin, end]
   const int64_t c_lo = begin / chunk, c_hi = end > begin ? (end - 1) / chunk : c_lo - 1;
   g.nseg = (int)(c_hi - c_lo + 1);
   g.threads = SEED_THREADS;
@@ -903,7 +1085,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   if (g.blocks <= 0 || d.nslots == 0) return hipSuccess;
   SeedArgs a;
   a.text = d_text; a.n = n; a.begin = begin; a.end = end;
-  a.chunk_len = g.seg_len; a.chunk0 = begin / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
+  a.chunk_len = g.seg_len; a.chunk0 = (d.edits && begin > d.edits ? begin - d.edits : (d.edits ? 0 : begin)) / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;                                                   // one run ~ one chunk per CU
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
@@ -914,7 +1096,9 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
   a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
-  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code; a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
+  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code;
+  a.edits = d.edits; a.maxlen = d.maxlen;
+  memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
@@ -923,7 +1107,8 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   hipError_t ce = hipMemcpyAsync(d.d_args, &a, sizeof(a), hipMemcpyHostToDevice, st);
   if (ce != hipSuccess) return ce;
   const dim3 grid(g.blocks), block(SEED_THREADS);
-  if (d.halves) hipLaunchKernelGGL((pm_seed_scan<0, 0, true>), grid, block, SEED_LDS_BYTES, st, a);
+  if (d.edits) hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, a);
+  else if (d.halves) hipLaunchKernelGGL((pm_seed_scan<0, 0, true>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1, false>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20 && d.mode == 2) hipLaunchKernelGGL((pm_seed_scan<20, 2, false>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20) hipLaunchKernelGGL((pm_seed_scan<20, 0, false>), grid, block, SEED_LDS_BYTES, st, a);

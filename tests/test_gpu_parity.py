@@ -355,3 +355,37 @@ def test_iupac_wildcards_inexact(seed):
                                     assert (a["start"], a["end"], a["editdist"], a["value"]) == (st, en, ed, val), (seed, h)
                         pm.close()
     assert total > 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_edit_distance_seed_plan(seed):
+    """filter_bitvec / shift_and_inexact with edits (-k 1, -k 2) on the seed kernels: displaced-piece
+    seeds, per-seed automaton run, device dedup -- raw candidates and final hits equal the oracle's,
+    normalized and raw streams, incl. the stream start (prefix rows), N runs and a short entry."""
+    rng = np.random.default_rng(1200 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(2000, 9000)), n_runs=3, repeats=(seed % 2 == 0), short=True)
+    L = int(rng.integers(20, 27))
+    pats = [p for p in synth.make_patterns(rng, ents, int(rng.integers(30, 200)), length=L, planted=0.8, indel_frac=0.5, extras=False)
+            if 20 <= len(p) <= 32]
+    pats.append(ents[0][2:2 + L])                       # a pattern whose first two characters lie before the stream start
+    pats.append(ents[0][:L])
+    table = synth.table_for(ents)
+    raw = np.frombuffer(synth.stream(ents), dtype=np.uint8)
+    codes = synth.normalize(synth.stream(ents), table)
+    total = 0
+    for stream_codes, tbl in ((codes, table), (raw, None)):
+        text = O.Text(stream_codes, tbl)
+        for k in (2, 1):
+            for sem in (sat_amd.SEM_SHIFT_AND_INEXACT, sat_amd.SEM_FILTER_BITVEC):
+                want = O.sorted_tuples(O.find_all(text, pats, engine=sem, k=k, indels=True))
+                for chunk in (1 << 26, 1500):
+                    pm = sat_amd.PatternMatch(k=k, indels=True, semantics=sem, kernel=sat_amd.KERNEL_SEED)
+                    for i, p in enumerate(pats):
+                        pm.add_pattern(p, i + 1)
+                    pm.init(stream_codes, tbl)
+                    assert pm.selected() == (sem, sat_amd.KERNEL_SEED)
+                    got = sat_amd.sorted_tuples(pm.find_all(chunk=chunk))
+                    pm.close()
+                    assert got == want, (seed, tbl is None, k, sem, chunk, len(got), len(want))
+                total += len(want)
+    assert total > 0
