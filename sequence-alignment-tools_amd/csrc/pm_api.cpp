@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <chrono>
 #include <thread>
 #include <unordered_map>
 
@@ -59,6 +60,10 @@ struct pm_handle {
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
   bool edits_dev = false;             // filter_bitvec / shift_and_inexact -k on the seed kernels: records deduplicated after the scan
+  std::vector<pm_hit> start_cache;    // edits: candidates that end in the first Lw+2k+2 characters (whole-prefix scans only)
+  bool start_cached = false;
+  uint8_t *d_dp_codes = nullptr;      // device DP (pm_cluster_dp): 32 stream codes per pattern, exact zones
+  int32_t *d_dp_esb = nullptr, *d_dp_eeb = nullptr;
   pm_hit *d_ext = nullptr;            // its output (swapped with d_cands after every scan)
   uint8_t *d_half_codes = nullptr, *d_half_len = nullptr;
   int32_t *d_hesb = nullptr, *d_heeb = nullptr;
@@ -166,7 +171,8 @@ static void free_device(pm_handle *h) {
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
   if (h->d_cands) (void)hipFree(h->d_cands);
-  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb}; for (void *q : hx) if (q) (void)hipFree(q); }
+  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb, h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb}; for (void *q : hx) if (q) (void)hipFree(q); }
+  h->d_dp_codes = nullptr; h->d_dp_esb = h->d_dp_eeb = nullptr;
   h->d_ext = nullptr; h->d_half_codes = h->d_half_len = nullptr; h->d_hesb = h->d_heeb = nullptr;
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -299,6 +305,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
   h->seed_flags = false;
+  h->start_cached = false; h->start_cache.clear();
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
   if (want_seed && !seed_eligible(h, &why)) {
@@ -495,6 +502,8 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   return PM_OK;
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // sort workspace shared by pm_finalize_device (clustering) and the edit-distance dedup
 static int ensure_sort_workspace(pm_handle *h, size_t n, bool with_out) {
   if (h->ckeys_cap < n || !h->d_keys) {
@@ -525,8 +534,10 @@ static int ensure_sort_workspace(pm_handle *h, size_t n, bool with_out) {
 // leave with the dedup.
 static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
   const int k = h->cfg.k;
-  const int64_t T = std::min<int64_t>(std::min<int64_t>(h->n, h->scan_end), h->sd.Lw + 2 * k + 2);
+  const int64_t Tfull = std::min<int64_t>(h->n, h->sd.Lw + 2 * k + 2);
+  const int64_t T = std::min<int64_t>(Tfull, h->scan_end);
   if (T <= 0) return PM_OK;
+  if (T == Tfull && h->start_cached) { *extra = h->start_cache; return PM_OK; }   // same stream, same patterns: computed once
   uint8_t head[64] = {0};
   if (h->h_text) memcpy(head, h->h_text, (size_t)T);
   else HIP_TRY(h, hipMemcpy(head, h->d_text, (size_t)T, hipMemcpyDeviceToHost));
@@ -535,11 +546,14 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
     const int L = (int)s.size();
     uint64_t R[3] = {0, 1, 3};
     const uint64_t last = 1ull << (L - 1);
+    uint64_t M[4] = {0, 0, 0, 0};                       // positions of A, C, G, T (the only pattern characters of the seed family)
+    int code[4];
+    for (int q = 0; q < 4; ++q) code[q] = h->alpha.nch[(unsigned char)"ACGT"[q]];
+    for (int i = 0; i < L; ++i) for (int q = 0; q < 4; ++q) if (s[i] == "ACGT"[q]) M[q] |= 1ull << i;
     for (int64_t t = 0; t < T; ++t) {
       const int c = head[t];
       if (c == h->eos_code) { R[0] = R[1] = R[2] = 0; continue; }
-      uint64_t U = 0;
-      for (int i = 0; i < L; ++i) if (h->alpha.nch[(unsigned char)s[i]] == c) U |= 1ull << i;
+      const uint64_t U = c == code[0] ? M[0] : c == code[1] ? M[1] : c == code[2] ? M[2] : c == code[3] ? M[3] : 0;
       const uint64_t x0 = (R[0] << 1) | 1, m1 = x0 | R[0], n0 = x0 & U;
       const uint64_t x1 = (R[1] << 1) | 1, n1 = (x1 & U) | m1 | (n0 << 1) | 1 | n0, m2 = x1 | R[1];
       const uint64_t x2 = (R[2] << 1) | 1, n2 = (x2 & U) | m2 | (n1 << 1) | 1 | n1;
@@ -551,6 +565,7 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
       }
     }
   }
+  if (T == Tfull && h->scan_begin == 0) { h->start_cache = *extra; h->start_cached = true; }
   return PM_OK;
 }
 
@@ -627,11 +642,12 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     }
     int rc = ensure_sort_workspace(h, tot, false);
     if (rc) return rc;
+    const double td0 = now_ms();
     HIP_TRY(h, dedup_device(h->d_cands, tot, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes, h->d_cands, h->d_fcounts, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last_count = (size_t)h->h_fcounts[0];
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] edits: %zu raw records (with holes) -> %zu unique candidates\n", tot, h->last_count);
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] edits: %zu raw records (with holes) -> %zu unique candidates, dedup %.1f ms\n", tot, h->last_count, now_ms() - td0);
     if (n_out) *n_out = h->last_count;
     h->last_launches += 3;
     return PM_OK;
@@ -758,6 +774,7 @@ pm_hit make_hit(int64_t end, uint64_t pid, int k) {
 // candidates by pattern (counting sort, O(n)) and cutting each pattern's ends at gaps > 2k+1.
 int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to, bool last,
                            std::vector<pm_hit> &outv) {
+  const double tf0 = now_ms();
   const size_t np = h->pats.size();
   const int k = h->cfg.k, win = 2 * k + 1;
   const bool indels = h->cfg.indels != 0;
@@ -815,8 +832,10 @@ int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
     if (c.first > (int64_t)L + k) ws = c.first - L - k;             // pattern_alignment.cc:137-139
     wins.push_back(Window{ws, (int32_t)(c.last - ws), 0});
   }
+  const double tf1 = now_ms();
   int rc = fetch_windows(h, wins);
   if (rc) return rc;
+  const double tf2 = now_ms();
   AlignParams prm; prm.k = k; prm.indels = indels; prm.eos = (uint8_t)h->cfg.eos;
   prm.wc = h->cfg.wildcards != 0; prm.tn = h->cfg.text_n != 0;
   // one DP per cluster; the clusters are independent: slices per host thread, results kept in order
@@ -841,6 +860,7 @@ int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
   }
   for (size_t wi = 0; wi < need_dp.size(); ++wi)
     if (res[wi].ok) outv.push_back(make_hit(res[wi].end, h->pats[need_dp[wi].pid - 1].id, res[wi].value));   // :135
+  if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] filter_bitvec host stage: cluster %.1f ms, windows %.1f ms, %zu DPs %.1f ms\n", tf1 - tf0, tf2 - tf1, need_dp.size(), now_ms() - tf2);
   return PM_OK;
 }
 
@@ -1041,6 +1061,9 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
   const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT;
   bool cluster = h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.indels && h->cfg.k <= 3 && h->pats.size() < ((size_t)1 << 22);
   if (cluster) for (const Pattern &p : h->pats) if (p.esb || p.eeb) { cluster = false; break; }
+  // edits on the seed family (A,C,G,T patterns of <= 32 characters): clusters and their DPs on the device
+  const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && h->pats.size() < ((size_t)1 << 22);
+  if (cluster_dp) cluster = true;
   if (!passthrough && !cluster) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this option set needs the host stage (pm_finalize)");
   if (passthrough) {
     if (n > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
@@ -1061,14 +1084,38 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
       HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
     }
   }
+  if (cluster_dp && !h->d_dp_codes) {
+    const size_t np = h->pats.size();
+    std::vector<uint8_t> codes(np * 32, 0);
+    std::vector<int32_t> es(np), ee(np);
+    for (size_t i = 0; i < np; ++i) {
+      for (size_t q = 0; q < h->pats[i].s.size() && q < 32; ++q) codes[i * 32 + q] = (uint8_t)h->alpha.nch[(unsigned char)h->pats[i].s[q]];
+      es[i] = h->pats[i].esb; ee[i] = h->pats[i].eeb;
+    }
+    HIP_TRY(h, hipMalloc((void **)&h->d_dp_codes, codes.size() ? codes.size() : 32));
+    HIP_TRY(h, hipMalloc((void **)&h->d_dp_esb, np ? np * 4 : 4));
+    HIP_TRY(h, hipMalloc((void **)&h->d_dp_eeb, np ? np * 4 : 4));
+    if (np) {
+      HIP_TRY(h, hipMemcpy(h->d_dp_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_dp_esb, es.data(), np * 4, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_dp_eeb, ee.data(), np * 4, hipMemcpyHostToDevice));
+    }
+  }
   // carried candidates from an earlier call join the batch on the host side (they are few)
   std::vector<pm_hit> hostpart;
   hostpart.swap(h->carry);
+  const double tfd0 = now_ms();
+  if (cluster_dp)
+    HIP_TRY(h, cluster_dp_device(src, n, h->cfg.k, true, scanned_to, last, h->d_text, h->n, h->eos_code, h->d_dp_codes, h->d_fpat_len,
+                                 h->d_dp_esb, h->d_dp_eeb, h->d_fpat_id, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes,
+                                 h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
+  else
   HIP_TRY(h, cluster_device(src, n, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, h->d_keys, h->d_keys_alt,
                             h->d_ctemp, h->ctemp_bytes, h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const size_t nfin = (size_t)h->h_fcounts[0], nleft = (size_t)h->h_fcounts[1];
+  const double tfd1 = now_ms();
   if (nleft) {
     const size_t at = hostpart.size();
     hostpart.resize(at + nleft);
@@ -1083,6 +1130,7 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
   if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));
   if (!extra.empty()) memcpy(out + nfin, extra.data(), extra.size() * sizeof(pm_hit));
   const size_t tot = nfin + extra.size();
+  if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] finalize_device: %zu records, device %.1f ms (%zu finals, %zu left for the host), host part + copies %.1f ms\n", n, tfd1 - tfd0, nfin, nleft, now_ms() - tfd1);
   if (flags & PM_FINALIZE_SORTED) std::sort(out, out + tot, by_end_pid);
   if (n_out) *n_out = tot;
   return PM_OK;

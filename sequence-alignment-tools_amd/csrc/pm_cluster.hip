@@ -106,7 +106,162 @@ __global__ void pm_dedup_unpack(const uint64_t *keys, size_t n, pm_hit *out, uns
   }
 }
 
+// ---- filter_bitvec with edits: clustering and the banded DP per cluster on the device ------------
+// editdist_alignment::align (reference pattern_alignment.cc:117-705) as pm_align.cpp restates it,
+// on stream codes (the patterns of the seed family are A,C,G,T, so code equality is character
+// equality), band cells in thread-private memory as (value, flags) bytes.  Returns true and
+// (*end, *value) when the alignment's value is <= k.
+constexpr int DP_MAXL = 32, DP_MAXDELTA = 10, DP_MAXW = DP_MAXDELTA + 2 * 3 + 2;
+enum : uint8_t { D_EQ = 2, D_SUB = 8, D_INS = 16, D_DEL = 32, D_VIOL = 64, D_END = 128 };
+
+__device__ bool device_editdist(const uint8_t *text, int64_t n, int64_t end, int64_t end2, const uint8_t *pat, int L,
+                                int lconst, int rconst, int k, bool indels, int eos, int64_t *out_end, int *out_value) {
+  uint8_t dp[(DP_MAXL + 1) * DP_MAXW], fl[(DP_MAXL + 1) * DP_MAXW];
+  const int viol = 5 * k + 1, b = indels ? k : 0;
+  int64_t ws = 0;
+  if (end > (int64_t)L + k) ws = end - L - k;                      // :137-139
+  const int buflen = (int)(end2 - ws), delta = (int)(end2 - end);
+  const int W = delta + 2 * b + 2;
+  auto at = [&](int p, int t) { return p * W + (t - (p - b)); };
+  auto tch = [&](int t) -> int { const int64_t q = ws + (buflen - t); return q >= 0 && q < n ? (int)text[q] : 0; };   // win[buflen - t]
+  int lbexact = 0, rbexact = L + 1;                                // :230-233
+  if (lconst > 0) rbexact = L + 1 - lconst;
+  if (rconst > 0) lbexact = rconst;
+  dp[at(0, 0)] = 0; fl[at(0, 0)] = D_END;
+  for (int p = 1, ub = b < L ? b : L; p <= ub; ++p) {              // column 0 (:253-268)
+    const int i = at(p, 0);
+    if (!indels || p < lbexact || p >= rbexact) { dp[i] = (uint8_t)viol; fl[i] = D_VIOL; }
+    else { dp[i] = (uint8_t)(dp[at(p - 1, 0)] + 1); fl[i] = D_DEL; }
+  }
+  for (int t = 1, ub = buflen < delta + b ? buflen : delta + b; t <= ub; ++t) {   // row 0 (:276-294)
+    const int i = at(0, t);
+    if (t <= delta) { dp[i] = 0; fl[i] = D_END; }
+    else if (!indels || lbexact > 0) { dp[i] = (uint8_t)viol; fl[i] = D_VIOL; }
+    else { dp[i] = (uint8_t)(dp[at(0, t - 1)] + 1); fl[i] = D_INS; }
+  }
+  for (int p = 1; p <= L; ++p) {                                   // :296-437
+    const int lb = p - b > 1 ? p - b : 1, ub = buflen < p + delta + b ? buflen : p + delta + b;
+    const int pc = pat[L - p];
+    const bool zone_sub = (p <= lbexact || p >= rbexact), zone_ins = (p < lbexact || p >= rbexact);
+    int rowmin = viol;
+    for (int t = lb; t <= ub; ++t) {
+      const int tc = tch(t);
+      int v, v1; uint8_t ac;
+      if (tc == pc) { v = dp[at(p - 1, t - 1)]; ac = D_EQ; }
+      else if (tc == eos || zone_sub) { v = viol; ac = D_VIOL; }
+      else { v = dp[at(p - 1, t - 1)] + 1; ac = D_SUB; }
+      if (tc == eos || !indels || t <= lb || zone_ins) {
+        if (viol < v) { v = viol; ac = D_VIOL; }
+      } else {
+        v1 = dp[at(p, t - 1)] + 1;
+        if (v1 < v) { v = v1; ac = D_INS; } else if (v1 == v) ac |= D_INS;
+      }
+      if (!indels || t >= ub || zone_sub) {
+        if (viol < v) { v = viol; ac = D_VIOL; }
+      } else {
+        v1 = dp[at(p - 1, t)] + 1;
+        if (v1 < v) { v = v1; ac = D_DEL; } else if (v1 == v) ac |= D_DEL;
+      }
+      const int i = at(p, t);
+      dp[i] = (uint8_t)v; fl[i] = ac;
+      rowmin = rowmin < v ? rowmin : v;
+    }
+    if (rowmin > k) return false;                                  // :425-436
+  }
+  int best = L - b < buflen ? L - b : buflen;                      // :443-475
+  if (best < 0) best = 0;
+  int bestval = dp[at(L, best)];
+  for (int c = best + 1, ub = buflen < L + delta + b ? buflen : L + delta + b; c <= ub; ++c) {
+    const int v = dp[at(L, c)];
+    if (v < bestval || (v <= bestval && (fl[at(L, c)] & (D_EQ | D_SUB)))) { bestval = v; best = c; }
+  }
+  int p = L, t = best;
+  if (t < p - b || t > p + b + delta) return false;                // :482-490
+  int last = 0;                                                    // 0 none, 1 eq, 2 sub, 3 ins, 4 del
+  for (int guard = 0; guard < 4 * (DP_MAXL + DP_MAXW); ++guard) {  // traceback (:514-590): only the end column matters here
+    const uint8_t ac = fl[at(p, t)];
+    if (ac & D_END) break;
+    const bool match = ac & (D_EQ | D_SUB), sub = ac & D_SUB, ins = ac & D_INS, del = ac & D_DEL;
+    if (match && !((last == 3 && ins) || (last == 4 && del))) {
+      --p; --t;
+      if ((ac & D_EQ) && !(last == 2 && sub)) last = 1;
+      else if (sub) last = 2;
+    } else if (del) { --p; last = 4; }
+    else if (ins) { --t; last = 3; }
+    else if (ac & D_VIOL) { p = 0; t = 0; break; }
+    else return false;
+  }
+  *out_end = end2 - t;                                             // :603-610
+  *out_value = bestval;
+  return bestval <= k;
+}
+
+__global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels, int64_t scanned_to, int last,
+                              const uint8_t *text, int64_t ntext, int eos,
+                              const uint8_t *pat_codes, const uint8_t *pat_len, const int32_t *esb, const int32_t *eeb,
+                              const uint32_t *pat_id, pm_hit *out, unsigned long long *out_count,
+                              pm_hit *left, unsigned long long *left_count) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == DEDUP_HOLE) return;
+  const int win = 2 * k + 1;
+  const uint32_t pid = (uint32_t)(key >> 42);
+  const int64_t end = (int64_t)((key >> 2) & 0xffffffffffull);
+  if (i > 0) {
+    const uint64_t pk = keys[i - 1];
+    if ((uint32_t)(pk >> 42) == pid && end - (int64_t)((pk >> 2) & 0xffffffffffull) <= win) return;   // not a cluster head
+  }
+  int64_t prev = end;
+  size_t j = i + 1;
+  for (; j < n; ++j) {                                             // chain: next candidate within 2k+1 (filter_bitvec.cc:103-116)
+    const uint64_t nk = keys[j];
+    const int64_t ne = (int64_t)((nk >> 2) & 0xffffffffffull);
+    if ((uint32_t)(nk >> 42) != pid || ne - prev > win) break;
+    prev = ne;
+  }
+  const int L = pat_len[pid - 1];
+  const bool incomplete = !last && scanned_to < prev + win;        // :118-121
+  if (incomplete || prev - end > DP_MAXDELTA || L > DP_MAXL || k > 3) {   // host stage: may still grow / long repeat cluster
+    for (size_t t = i; t < j; ++t) {
+      if (t > i && (keys[t] >> 2) == (keys[t - 1] >> 2)) continue;  // duplicate
+      const unsigned long long o = atomicAdd(left_count, 1ull);
+      pm_hit h;
+      h.pid = pid; h.end = (int64_t)((keys[t] >> 2) & 0xffffffffffull); h.k = (uint8_t)(keys[t] & 3u);
+      h.aux[0] = h.aux[1] = h.aux[2] = 0;
+      left[o] = h;
+    }
+    return;
+  }
+  int64_t rend = 0; int rval = 0;
+  if (device_editdist(text, ntext, end, prev, pat_codes + (size_t)(pid - 1) * 32, L, esb[pid - 1], eeb[pid - 1], k, indels != 0, eos, &rend, &rval)) {
+    const unsigned long long o = atomicAdd(out_count, 1ull);
+    pm_hit h;
+    h.pid = pat_id[pid - 1]; h.end = rend; h.k = (uint8_t)rval; h.aux[0] = h.aux[1] = h.aux[2] = 0;
+    out[o] = h;
+  }
+}
+
 }  // namespace
+
+// Clustering + one DP per cluster for filter_bitvec with edits.  Records in any order (duplicates and
+// holes allowed); finals to d_out / d_counts[0], records the host stage must look at to d_left / d_counts[1].
+hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, int64_t scanned_to, bool last,
+                             const uint8_t *d_text, int64_t ntext, int eos_code,
+                             const uint8_t *d_pat_codes, const uint8_t *d_pat_len, const int32_t *d_esb, const int32_t *d_eeb,
+                             const uint32_t *d_pat_id, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                             pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), st);
+  if (e != hipSuccess || n == 0) return e;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((n + threads - 1) / threads);
+  hipLaunchKernelGGL(pm_dedup_pack, dim3(blocks), dim3(threads), 0, st, d_in, n, d_keys);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(pm_cluster_dp, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, k, indels ? 1 : 0, scanned_to, last ? 1 : 0,
+                     d_text, ntext, eos_code, d_pat_codes, d_pat_len, d_esb, d_eeb, d_pat_id, d_out, d_counts, d_left, d_counts + 1);
+  return hipGetLastError();
+}
 
 // d_out may alias d_in (the keys are a copy).  *d_count receives the number of unique records.
 hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,

@@ -93,6 +93,12 @@ constexpr int SEED_OUT_BLOCK = 64;               // slots a wave reserves per at
 hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                         pm_hit *d_out, unsigned long long *d_count, hipStream_t st);
 
+hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, int64_t scanned_to, bool last,
+                             const uint8_t *d_text, int64_t ntext, int eos_code,
+                             const uint8_t *d_pat_codes, const uint8_t *d_pat_len, const int32_t *d_esb, const int32_t *d_eeb,
+                             const uint32_t *d_pat_id, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                             pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
+
 // ---- seed extension DP on the GPU (pm_extend.hip) ---------------------------------------------
 hipError_t extend_seeds(const uint8_t *d_text, int64_t n, const pm_hit *d_seeds, size_t nseeds,
                         const uint8_t *d_half_codes, const uint8_t *d_half_len, const int32_t *d_esb, const int32_t *d_eeb,

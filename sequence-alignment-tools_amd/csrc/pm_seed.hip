@@ -412,11 +412,18 @@ __device__ __forceinline__ pm_hit edit_record(int64_t end, uint32_t pid, uint32_
   return hh;
 }
 
+// The automaton run is ~500 instructions: out of line even on the main path (the call's register
+// traffic is small next to it, and the kernel stays within the instruction cache); the caller keeps
+// the wave-uniform block-reserved emission.
+__device__ __noinline__ uint32_t edits_verify_call(const SeedArgs *ap, int64_t p, uint32_t pi, uint32_t *pid) {
+  return edits_verify(*ap, p, pi, pid);
+}
+
 // rare paths (second match in a bucket, probe continuation): one atomic per record
 __device__ __noinline__ void verify_edits(const SeedArgs *ap, int64_t p, uint32_t pi) {
   const SeedArgs &a = *ap;
   uint32_t pid = 0;
-  const uint32_t res = edits_verify(a, p, pi, &pid);
+  const uint32_t res = edits_verify_call(ap, p, pi, &pid);
   for (int d = 0; d < 5; ++d) {
     const uint32_t lvl1 = (res >> (4 * d)) & 15u;
     const int64_t e = p - 1 + d;
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       }
       if (EDITS) {                                                 // wave-uniform: automaton verify, block-reserved output
         uint32_t pid = 0, res = 0;
-        if ((mm & 255u) && !(a.debug & 4)) res = edits_verify(a, p, pidx, &pid);
+        if ((mm & 255u) && !(a.debug & 4)) res = edits_verify_call(a.self, p, pidx, &pid);
 #pragma unroll 1
         for (int d = 0; d < 5; ++d) {
           const uint32_t lvl1 = (res >> (4 * d)) & 15u;

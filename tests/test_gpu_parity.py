@@ -205,13 +205,46 @@ def test_device_finalize_equals_host_finalize():
         b = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
         assert sorted(a + b) == host, (k, "split")
         pm.close()
-    pm = sat_amd.PatternMatch(k=1, indels=True)
+    pm = sat_amd.PatternMatch(k=1, indels=True)         # exact_halves: its sequential rule stays on the host
     pm.add_pattern("ACGTACGTACGTACGTACGT", 1)
     pm.init(codes, table)
     pm.scan_candidates(0, n, to_host=False)
     with pytest.raises(sat_amd.PmError):
         pm.finalize_device(n)
     pm.close()
+
+
+@pytest.mark.parametrize("case", ["varlen_repeats", "dense_indels", "small_mixed"])
+def test_device_cluster_dp_equals_host_stage(case):
+    """filter_bitvec with edits on the seed family: pm_finalize_device (sort, chain clusters and the
+    banded DP with the reference's end-column and traceback rules on the GPU) == the host stage and
+    the golden hits; also in two ranges (clusters that may still grow are held back)."""
+    c, codes, table, allp = load([p for p in CASES if case in p][0])
+    n = codes.size
+    pats = [p for p in allp if 20 <= len(p) <= 32]
+    if len(pats) < 4:
+        pytest.skip("patterns of this fixture are shorter than 20")
+    for k in (2, 1):
+        pm = sat_amd.PatternMatch(k=k, indels=True, semantics=sat_amd.SEM_FILTER_BITVEC, kernel=sat_amd.KERNEL_SEED)
+        for i, p in enumerate(pats):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        cands = pm.scan_candidates(0, n)
+        host = sat_amd.sorted_tuples(pm.finalize(cands, n, last=True))
+        want = O.sorted_tuples(O.find_all(O.Text(codes, table), pats, engine=5, k=k, indels=True))
+        assert host == want
+        pm.reset()
+        pm.scan_candidates(0, n, to_host=False)
+        dev = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
+        assert dev == host and len(host) > 0, (case, k, len(dev), len(host))
+        pm.reset()
+        cut = n // 2
+        pm.scan_candidates(0, cut, to_host=False)
+        a = sat_amd.sorted_tuples(pm.finalize_device(cut, last=False))
+        pm.scan_candidates(cut, n, to_host=False)
+        b = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
+        assert sorted(a + b) == host, (case, k, "split")
+        pm.close()
 
 
 def test_cli_lines_via_align_hits():
