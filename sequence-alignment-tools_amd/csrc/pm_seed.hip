@@ -68,6 +68,7 @@ struct SeedArgs {
   int halves, hk;                       // exact_halves -k: patterns are halves, partner prefilter for hk edits
   int edits;                            // > 0: filter_bitvec / shift_and_inexact with indels; pat_codes holds 32-byte automaton records
   uint32_t emask_a[SEED_MAX_COMBOS], emask_b[SEED_MAX_COMBOS];   // byte masks (low window word) of the combo's first and second piece
+  uint32_t eadj[SEED_MAX_COMBOS];       // bit 0: first and second piece adjacent, bit 1: second and third adjacent
   int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
                                         // partner's stream window is known before the half's record is read
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
@@ -352,19 +353,21 @@ __device__ __forceinline__ uint32_t edits_verify(const SeedArgs &a, int64_t p, u
   const uint4 M = rec[0], r = rec[1];
   const int L = (int)(r.x & 0xffu), k = a.edits;
   *pid = r.y;
-  const int64_t tend = p + 3 < a.n ? p + 3 : a.n;                 // characters [t0, tend) are consumed
-  int64_t t0 = p - 1 - L - k;
-  uint32_t R0 = 0, R1 = 0, R2 = 0;
-  if (t0 <= 0) { t0 = 0; R1 = 1u; R2 = 3u; }                      // true start of the stream: l prefix bits in row l (:162-164)
-  const uint32_t last = 1u << (L - 1);
+  // characters [base + skip, p+3) are consumed: maxlen+k+4 of them, so that every end p-1..p+3 has
+  // its L+k characters; an earlier start only adds true history
   const int nch = (a.maxlen + k + 4 + 15) >> 4;                   // wave-uniform number of 16-byte pieces
+  const int skip = 16 * nch - (a.maxlen + k + 4);                 // wave-uniform: leading characters of the first piece not needed
   const int64_t base = p + 3 - 16 * (int64_t)nch;
+  uint32_t R0 = 0, R1 = 0, R2 = 0;
+  if (base + skip <= 0) { R1 = 1u; R2 = 3u; }                     // true start of the stream: l prefix bits in row l (:162-164)
+  const uint32_t last = 1u << (L - 1);
   uint32_t res = 0;
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
     const int64_t off = base + 16 * c;
     uint4 v;
-    if (off >= 0 && off + 16 <= a.n) __builtin_memcpy(&v, a.text + off, 16);
+    const bool inside = off >= 0 && off + 16 <= a.n;
+    if (inside) __builtin_memcpy(&v, a.text + off, 16);
     else {
       uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -378,27 +381,31 @@ __device__ __forceinline__ uint32_t edits_verify(const SeedArgs &a, int64_t p, u
     const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-      const int64_t t = off + b;
-      const bool live = t >= t0 && t < tend;
+      if (c == 0 && b < skip) continue;                            // wave-uniform
       const uint32_t ch = (vw[b >> 2] >> (8 * (b & 3))) & 0xffu;
       uint32_t U;
       if (a.ascii) U = ch == 'A' ? M.x : ch == 'C' ? M.y : ch == 'G' ? M.z : ch == 'T' ? M.w : 0u;
-      else U = ch == 0 ? M.x : ch == 1 ? M.y : ch == 2 ? M.z : ch == 3 ? M.w : 0u;
-      const bool eos = (int)ch == a.eos_code;
+      else {
+        const uint32_t u01 = (ch & 1u) ? M.y : M.x, u23 = (ch & 1u) ? M.w : M.z;
+        U = ch > 3u ? 0u : ((ch & 2u) ? u23 : u01);
+      }
       // one character (pm_bitpar.hip step<K, true>): substitution, insertion and deletion terms
       const uint32_t x0 = (R0 << 1) | 1u, m1 = x0 | R0;
-      const uint32_t n0 = x0 & U;
+      uint32_t n0 = x0 & U;
       const uint32_t x1 = (R1 << 1) | 1u;
-      const uint32_t n1 = (x1 & U) | m1 | (n0 << 1) | 1u | n0;
-      const uint32_t m2 = x1 | R1;
-      const uint32_t x2 = (R2 << 1) | 1u;
-      const uint32_t n2 = (x2 & U) | m2 | (n1 << 1) | 1u | n1;
-      if (live) { R0 = eos ? 0u : n0; R1 = eos ? 0u : n1; R2 = eos ? 0u : n2; }
-      // ends p-1 .. p+3 are the positions after the characters p-2 .. p+2
-      const int d = (int)(t - (p - 2));
-      if (live && d >= 0 && d <= 4) {
-        const uint32_t lvl = (R0 & last) ? 1u : (R1 & last) ? 2u : (k >= 2 && (R2 & last)) ? 3u : 0u;
-        res |= lvl << (4 * d);
+      uint32_t n1 = (x1 & U) | m1 | (n0 << 1) | 1u | n0;
+      uint32_t n2 = 0;
+      if (k >= 2) {                                                // wave-uniform
+        const uint32_t m2 = x1 | R1, x2 = (R2 << 1) | 1u;
+        n2 = (x2 & U) | m2 | (n1 << 1) | 1u | n1;
+      }
+      bool live = true;
+      if (!inside) { const int64_t t = off + b; live = t >= 0 && t < a.n; }   // only at the stream's ends
+      if ((int)ch == a.eos_code) { n0 = 0; n1 = 0; n2 = 0; }      // EOS clears every row
+      if (live) { R0 = n0; R1 = n1; R2 = n2; }
+      if (c == nch - 1 && b >= 11) {                               // ends p-1 .. p+3 = after the characters p-2 .. p+2
+        const uint32_t lvl = (R0 & last) ? 1u : (R1 & last) ? 2u : (R2 & last) ? 3u : 0u;
+        if (live) res |= lvl << (4 * (b - 11));
       }
     }
   }
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       const int s = 2 * (i - Lw + 33) + 2 * d;                     // 22 .. 60
       return s < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, s) : __builtin_amdgcn_alignbit(cur, prev1, s - 32);
     };
-    const uint32_t ema = EDITS ? a.emask_a[combo] : 0u, emb = EDITS ? a.emask_b[combo] : 0u;
+    const uint32_t ema = EDITS ? a.emask_a[combo] : 0u, emb = EDITS ? a.emask_b[combo] : 0u, eadj = EDITS ? a.eadj[combo] : 0u;
     // first stage, parts 1 and 2 for one displacement pattern (sa, sb = displacement of the combo's
     // first and second piece; compile-time constants at every call): 16 hashes, 16 LDS reads in
     // flight, three bit tests per window, verdicts funnelled into one register
@@ -798,7 +805,11 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     for (int v = 0; v < NV; ++v) {
       const int cost = (VD1[v] < 0 ? -VD1[v] : VD1[v]) + (VD2[v] < 0 ? -VD2[v] : VD2[v]);
       rems[v] = 0;
-      if (!EDITS || cost <= a.edits) rems[v] = tests(VD1[v] + VD2[v], VD1[v]);
+      // Pieces next to each other can only be pulled apart by characters inserted between them:
+      // the left one then sits further left (negative displacement).  A positive displacement
+      // would need a deleted character, which belongs to one of the two pieces.
+      const bool possible = !((VD1[v] > 0 && (eadj & 2u)) || (VD2[v] > 0 && (eadj & 1u)));
+      if (!EDITS || (cost <= a.edits && possible)) rems[v] = tests(VD1[v] + VD2[v], VD1[v]);
     }
     // part 3: compaction, one survivor per lane and round (ballot + mbcnt give the queue slots)
 #pragma unroll 1
@@ -1049,6 +1060,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   for (int c = 0; c < d->ncombos; ++c) {              // byte masks of the combo's first and second piece (edits: displaced pieces)
     d->emask_a[c] = t.r >= 3 && t.combos[c][0] < 4 ? 0xffu << (8 * t.combos[c][0]) : 0u;
     d->emask_b[c] = t.r >= 3 && t.combos[c][1] < 4 ? 0xffu << (8 * t.combos[c][1]) : 0u;
+    d->eadj[c] = t.r >= 3 ? ((t.combos[c][1] == t.combos[c][0] + 1 ? 1u : 0u) | (t.combos[c][2] == t.combos[c][1] + 1 ? 2u : 0u)) : 0u;
   }
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
@@ -1105,7 +1117,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
   a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code;
   a.edits = d.edits; a.maxlen = d.maxlen;
-  memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
+  memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); memcpy(a.eadj, d.eadj, sizeof(a.eadj)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
