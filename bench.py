@@ -259,6 +259,9 @@ def main():
 
     def finalize_rank0(ptr, cnt, scanned_to):
         """records in HBM -> final hits on the host of rank 0"""
+        if world > 1 and args.indels and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC:
+            # the clusters' DPs read stream text around every candidate; rank 0 holds only its own shard
+            raise SystemExit("bench.py --gpus>1: filter_bitvec with edits verifies against stream text, which rank 0 does not hold (DESIGN.md 5)")
         if dev_final[0]:
             try:
                 return pm.finalize_device(scanned_to, last=True, sort=False, d_cands=ptr, n=cnt, out=out_buf)
