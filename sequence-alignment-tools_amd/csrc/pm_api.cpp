@@ -60,6 +60,10 @@ struct pm_handle {
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
   bool edits_dev = false;             // filter_bitvec / shift_and_inexact -k on the seed kernels: records deduplicated after the scan
+  unsigned long long *d_seed_count = nullptr;   // edits: [0] unused, [1+t] seed records of tile t
+  uint64_t *d_seeds = nullptr;                  // edits: 8-byte seed records between the scan and the verify kernel
+  size_t seed_cap = 0;
+  unsigned long long h_seed_count[1 + 256] = {};
   std::vector<pm_hit> start_cache;    // edits: candidates that end in the first Lw+2k+2 characters (whole-prefix scans only)
   bool start_cached = false;
   uint8_t *d_dp_codes = nullptr;      // device DP (pm_cluster_dp): 32 stream codes per pattern, exact zones
@@ -171,7 +175,8 @@ static void free_device(pm_handle *h) {
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
   if (h->d_cands) (void)hipFree(h->d_cands);
-  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb, h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb}; for (void *q : hx) if (q) (void)hipFree(q); }
+  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb, h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_seed_count, h->d_seeds}; for (void *q : hx) if (q) (void)hipFree(q); }
+  h->d_seed_count = nullptr; h->d_seeds = nullptr;
   h->d_dp_codes = nullptr; h->d_dp_esb = h->d_dp_eeb = nullptr;
   h->d_ext = nullptr; h->d_half_codes = h->d_half_len = nullptr; h->d_hesb = h->d_heeb = nullptr;
   if (h->d_counter) (void)hipFree(h->d_counter);
@@ -485,7 +490,27 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-  if (h->kern == PM_KERNEL_SEED)
+  if (h->kern == PM_KERNEL_SEED && h->edits_dev)
+  {
+    // per pattern tile: scan kernel -> seed records in d_ext, verify kernel -> candidates in d_cands
+    // ~1 seed record per 8 bases at 200k patterns (key matches that pass the four-base-word test)
+    if (!h->d_seeds) {
+      if (h->seed_cap == 0) h->seed_cap = std::max<size_t>((size_t)(h->n / 6), (size_t)1 << 20);
+      HIP_TRY(h, hipMalloc((void **)&h->d_seeds, h->seed_cap * sizeof(uint64_t)));
+    }
+    if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, (1 + 256) * sizeof(unsigned long long)));
+    const int ntiles = 1 + (int)h->sd_more.size();
+    if (ntiles > 256) return fail(h, PM_E_UNSUPPORTED, "too many pattern tiles for the edit-distance plan");
+    HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, (1 + 256) * sizeof(unsigned long long), h->stream));
+    for (int t = 0; t < ntiles; ++t) {
+      EditStage es; es.d_seeds = h->d_seeds; es.d_seed_count = h->d_seed_count + 1 + t; es.seed_cap = h->seed_cap; es.tile = t;
+      const SeedDevice &d = t == 0 ? h->sd : h->sd_more[t - 1];
+      HIP_TRY(h, seed_launch(d, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 ? &h->geo : nullptr, &es));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    h->last_launches = 2 * ntiles;
+  }
+  else if (h->kern == PM_KERNEL_SEED)
   {
     HIP_TRY(h, seed_launch(h->sd, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
     for (SeedDevice &d : h->sd_more)
@@ -630,6 +655,17 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     h->last_launches += 1;
   }
   if (h->edits_dev) {
+    // the seed buffer of a tile must have held all its seed records
+    unsigned long long worst = 0;
+    for (int t = 0; t < 1 + (int)h->sd_more.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] edits: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", worst, h->seed_cap, cnt);
+    if (worst > h->seed_cap) {                                     // grow the seed buffer and tell the caller to scan again
+      (void)hipFree(h->d_seeds); h->d_seeds = nullptr;
+      h->seed_cap = (size_t)worst + (size_t)worst / 8 + 1024;
+      h->last_count = 0;
+      if (n_out) *n_out = h->cap + 1;                                // "> cap": pm_scan's retry condition
+      return fail(h, PM_E_OVERFLOW, "seed buffer was too small; it has been enlarged, scan the range again");
+    }
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
     if (h->scan_begin == 0) {

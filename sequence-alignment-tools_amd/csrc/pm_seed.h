@@ -64,8 +64,15 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
 void seed_free(SeedDevice *d);
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);
+// edit-distance plan: where the scan kernel puts its seed records (the verify kernel reads them)
+struct EditStage {
+  uint64_t *d_seeds = nullptr;                    // 8-byte records: pattern index << 40 | position
+  unsigned long long *d_seed_count = nullptr;     // zeroed by the caller before every launch
+  uint64_t seed_cap = 0;
+  int tile = 0;
+};
 hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
-                       ScanGeometry *geo_out);
+                       ScanGeometry *geo_out, const EditStage *es = nullptr);
 
 }  // namespace pm

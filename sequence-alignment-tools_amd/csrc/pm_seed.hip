@@ -67,6 +67,7 @@ struct SeedArgs {
   int eos_code;                         // stream code of the end-of-sequence character, -1 = none
   int halves, hk;                       // exact_halves -k: patterns are halves, partner prefilter for hk edits
   int edits;                            // > 0: filter_bitvec / shift_and_inexact with indels; pat_codes holds 32-byte automaton records
+  uint64_t *seed_out;                   // EDITS scan: 8-byte seed records (pattern index << 40 | position), ~0 = unused slot
   uint32_t emask_a[SEED_MAX_COMBOS], emask_b[SEED_MAX_COMBOS];   // byte masks (low window word) of the combo's first and second piece
   uint32_t eadj[SEED_MAX_COMBOS];       // bit 0: first and second piece adjacent, bit 1: second and third adjacent
   int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
@@ -412,6 +413,36 @@ __device__ __forceinline__ uint32_t edits_verify(const SeedArgs &a, int64_t p, u
   return res;
 }
 
+// q-gram lemma with positions, q = 4: k edits touch at most 4k of the 17 four-base words of the
+// pattern's last 20 bases; every untouched word sits in the stream within k positions of where the
+// seed (whose right-most piece is in place) expects it.  XOR of the packed pattern with the packed
+// stream at the 2k+1 displacements, zero test over 8-bit windows at 2-bit steps, OR, popcount:
+// random key matches pass with probability ~1e-6, real ones always (N and EOS pack to arbitrary
+// bases, which can only add words).
+__device__ __forceinline__ bool edits_plausible(const SeedArgs &a, int64_t p, uint32_t pi) {
+  const int k = a.edits;
+  if (p - 21 < 0 || p + 3 > a.n) return true;                     // stream ends: let the automaton decide
+  const uint2 pp = a.pat40[pi];
+  const uint64_t P = ((uint64_t)pp.y << 32) | pp.x;               // base j of the last 20 at bits 2j
+  uint64_t raw0, raw1, raw2;
+  __builtin_memcpy(&raw0, a.text + p - 21, 8);
+  __builtin_memcpy(&raw1, a.text + p - 13, 8);
+  __builtin_memcpy(&raw2, a.text + p - 5, 8);
+  const int sh = a.ascii ? 1 : 0;
+  const uint64_t T = (uint64_t)(pack4((uint32_t)raw0, sh) | (pack4((uint32_t)(raw0 >> 32), sh) << 8) |
+                                (pack4((uint32_t)raw1, sh) << 16) | (pack4((uint32_t)(raw1 >> 32), sh) << 24)) |
+                     ((uint64_t)(pack4((uint32_t)raw2, sh) | (pack4((uint32_t)(raw2 >> 32), sh) << 8)) << 32);   // stream p-21 .. p+2
+  uint64_t M = 0;
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) {
+    if (d < -k || d > k) continue;                                 // wave-uniform
+    const uint64_t x = (P ^ (T >> (2 * (2 + d)))) & 0xffffffffffull;
+    const uint64_t z = x | (x >> 2) | (x >> 4) | (x >> 6);
+    M |= ~(z | (z >> 1));
+  }
+  return __popcll(M & 0x155555555ull) >= 17 - 4 * k;               // words j = 0..16 at bits 2j
+}
+
 __device__ __forceinline__ pm_hit edit_record(int64_t end, uint32_t pid, uint32_t lvl1) {
   pm_hit hh;
   hh.end = end; hh.pid = pid; hh.k = (uint8_t)(lvl1 - 1u);
@@ -419,26 +450,16 @@ __device__ __forceinline__ pm_hit edit_record(int64_t end, uint32_t pid, uint32_
   return hh;
 }
 
-// The automaton run is ~500 instructions: out of line even on the main path (the call's register
-// traffic is small next to it, and the kernel stays within the instruction cache); the caller keeps
-// the wave-uniform block-reserved emission.
-__device__ __noinline__ uint32_t edits_verify_call(const SeedArgs *ap, int64_t p, uint32_t pi, uint32_t *pid) {
-  return edits_verify(*ap, p, pi, pid);
+__device__ __forceinline__ uint64_t edit_seed_record(int64_t p, uint32_t pi) {
+  return ((uint64_t)pi << 40) | ((uint64_t)p & 0xffffffffffull);
 }
 
-// rare paths (second match in a bucket, probe continuation): one atomic per record
+// rare paths (second match in a bucket, probe continuation): one atomic per seed record
 __device__ __noinline__ void verify_edits(const SeedArgs *ap, int64_t p, uint32_t pi) {
   const SeedArgs &a = *ap;
-  uint32_t pid = 0;
-  const uint32_t res = edits_verify_call(ap, p, pi, &pid);
-  for (int d = 0; d < 5; ++d) {
-    const uint32_t lvl1 = (res >> (4 * d)) & 15u;
-    const int64_t e = p - 1 + d;
-    if (lvl1 && e > a.begin && e <= a.end) {
-      const unsigned long long o = atomicAdd(a.counter, 1ull);
-      if (o < a.cap) a.out[o] = edit_record(e, pid, lvl1);
-    }
-  }
+  if (!edits_plausible(a, p, pi)) return;
+  const unsigned long long o = atomicAdd(a.counter, 1ull);
+  if (o < a.cap) a.seed_out[o] = edit_seed_record(p, pi);
 }
 
 // packed distance (2 bits per base) never exceeds the true one: a cheap necessary condition
@@ -604,12 +625,12 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     }
     ob_next += c; ob_left -= c;
   };
-  auto emit_edit = [&](bool pass, int64_t e, uint32_t pid, uint32_t lvl1) __attribute__((always_inline)) {
+  auto emit_edit = [&](bool pass, int64_t p, uint32_t pi) __attribute__((always_inline)) {
     const unsigned long long bal = __ballot(pass);
     if (bal == 0) return;
     const int c = __popcll(bal);
     if (c > ob_left) {
-      if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+      if (lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
       unsigned long long base = 0;
       if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
       ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
@@ -618,7 +639,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     }
     if (pass) {
       const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-      if (slot < a.cap) a.out[slot] = edit_record(e, pid, lvl1);
+      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, pi);
     }
     ob_next += c; ob_left -= c;
   };
@@ -649,15 +670,10 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
         pidx = slot & imask;
         if (!HALVES && !EDITS) pp = a.pat40[pidx];                   // halves / edits: their own record decides
       }
-      if (EDITS) {                                                 // wave-uniform: automaton verify, block-reserved output
-        uint32_t pid = 0, res = 0;
-        if ((mm & 255u) && !(a.debug & 4)) res = edits_verify_call(a.self, p, pidx, &pid);
-#pragma unroll 1
-        for (int d = 0; d < 5; ++d) {
-          const uint32_t lvl1 = (res >> (4 * d)) & 15u;
-          const int64_t e = p - 1 + d;
-          emit_edit(lvl1 != 0 && e > a.begin && e <= a.end, e, pid, lvl1);
-        }
+      if (EDITS) {                                                 // wave-uniform: three-base-word test, seeds out in reserved blocks
+        bool pass = false;
+        if ((mm & 255u) && !(a.debug & 4)) pass = edits_plausible(a, p, pidx);
+        emit_edit(pass, p, pidx);
       }
       if (HALVES) {                                                // wave-uniform: block-reserved output
         uint32_t pid = 0;
@@ -849,7 +865,50 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   drain();
   finish();
   process_q2();
-  if ((HALVES || EDITS) && lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+  if (HALVES && lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+  if (EDITS && lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
+}
+
+// Second kernel of the edit-distance plan: the seed list is dense (every lane has work), one seed
+// per lane, grid-stride; the seed count is read from device memory (no host round trip).
+struct EditVerifyArgs {
+  SeedArgs a;                           // text, records (pat_codes), eos, edits, maxlen, begin/end of the scan
+  const uint64_t *seeds;
+  const unsigned long long *nseeds;
+  unsigned long long seed_cap;
+};
+
+__global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
+  const SeedArgs &a = v.a;
+  unsigned long long n = *v.nseeds;
+  if (n > v.seed_cap) n = v.seed_cap;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long rounds = (n + stride - 1) / stride;     // same trip count for every lane: ballots below stay whole-wave
+  for (unsigned long long it = 0; it < rounds; ++it) {
+    const unsigned long long i = it * stride + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t res = 0, pid = 0;
+    int64_t p = 0;
+    if (i < n) {
+      const uint64_t sd = v.seeds[i];
+      if (sd != ~0ull) { p = (int64_t)(sd & 0xffffffffffull); res = edits_verify(a, p, (uint32_t)(sd >> 40), &pid); }
+    }
+#pragma unroll 1
+    for (int d = 0; d < 5; ++d) {
+      const uint32_t lvl1 = (res >> (4 * d)) & 15u;
+      const int64_t e = p - 1 + d;
+      const bool pass = lvl1 != 0 && e > a.begin && e <= a.end;
+      const unsigned long long bal = __ballot(pass);
+      if (bal == 0) continue;
+      const int lane = threadIdx.x & 63;
+      unsigned long long base = 0;
+      if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(a.counter, (unsigned long long)__popcll(bal));
+      base = __shfl(base, __ffsll((long long)bal) - 1);
+      if (pass) {
+        const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        if (slot < a.cap) a.out[slot] = edit_record(e, pid, lvl1);
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -1097,7 +1156,7 @@ ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end) {
 
 hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
-                       ScanGeometry *geo_out) {
+                       ScanGeometry *geo_out, const EditStage *es) {
   if (end > n) end = n;
   ScanGeometry g = seed_geometry(d, begin, end);
   if (geo_out) *geo_out = g;
@@ -1126,7 +1185,23 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   hipError_t ce = hipMemcpyAsync(d.d_args, &a, sizeof(a), hipMemcpyHostToDevice, st);
   if (ce != hipSuccess) return ce;
   const dim3 grid(g.blocks), block(SEED_THREADS);
-  if (d.edits) hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, a);
+  if (d.edits) {
+    // two kernels: the scan writes seed records (pattern, position) that passed the three-base-word
+    // test into es->d_seeds; pm_edits_verify runs the automaton over that dense list and writes
+    // the candidates to d_out.  *es->d_seed_count is zeroed by the caller (stream order).
+    if (!es || !es->d_seeds || !es->d_seed_count) return hipErrorInvalidValue;
+    SeedArgs sa = a;
+    sa.seed_out = es->d_seeds; sa.counter = es->d_seed_count; sa.cap = es->seed_cap;
+    // the rare out-of-line paths read the scan's view of the argument block
+    ce = hipMemcpyAsync(d.d_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st);
+    if (ce != hipSuccess) return ce;
+    hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, sa);
+    if ((ce = hipGetLastError()) != hipSuccess) return ce;
+    EditVerifyArgs v;
+    v.a = a;
+    v.seeds = es->d_seeds; v.nseeds = es->d_seed_count; v.seed_cap = es->seed_cap;
+    hipLaunchKernelGGL(pm_edits_verify, dim3(256 * 16), dim3(256), 0, st, v);
+  }
   else if (d.halves) hipLaunchKernelGGL((pm_seed_scan<0, 0, true>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1, false>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20 && d.mode == 2) hipLaunchKernelGGL((pm_seed_scan<20, 2, false>), grid, block, SEED_LDS_BYTES, st, a);
