@@ -48,7 +48,7 @@ struct SeedDevice {
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr;
   uint32_t *part32 = nullptr;
   bool halves = false; int hk = 0, hfast = 0, eos_code = -1, edits = 0;
-  uint32_t emask_a[SEED_MAX_COMBOS] = {}, emask_b[SEED_MAX_COMBOS] = {}, eadj[SEED_MAX_COMBOS] = {};
+  uint32_t emask_a[SEED_MAX_COMBOS] = {}, emask_b[SEED_MAX_COMBOS] = {}, evar[SEED_MAX_COMBOS] = {};
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
   int mode = 0;
   int k = 0, Lw = 0, pb = 0, r = 0, ncombos = 0, maxlen = 0;

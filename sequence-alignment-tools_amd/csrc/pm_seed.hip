@@ -69,7 +69,7 @@ struct SeedArgs {
   int edits;                            // > 0: filter_bitvec / shift_and_inexact with indels; pat_codes holds 32-byte automaton records
   uint64_t *seed_out;                   // EDITS scan: 8-byte seed records (pattern index << 40 | position), ~0 = unused slot
   uint32_t emask_a[SEED_MAX_COMBOS], emask_b[SEED_MAX_COMBOS];   // byte masks (low window word) of the combo's first and second piece
-  uint32_t eadj[SEED_MAX_COMBOS];       // bit 0: first and second piece adjacent, bit 1: second and third adjacent
+  uint32_t evar[SEED_MAX_COMBOS];       // bit v: displacement pattern v is tested for this combo (edit_cover on the host)
   int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
                                         // partner's stream window is known before the half's record is read
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       const int s = 2 * (i - Lw + 33) + 2 * d;                     // 22 .. 60
       return s < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, s) : __builtin_amdgcn_alignbit(cur, prev1, s - 32);
     };
-    const uint32_t ema = EDITS ? a.emask_a[combo] : 0u, emb = EDITS ? a.emask_b[combo] : 0u, eadj = EDITS ? a.eadj[combo] : 0u;
+    const uint32_t ema = EDITS ? a.emask_a[combo] : 0u, emb = EDITS ? a.emask_b[combo] : 0u, evar = EDITS ? a.evar[combo] : 0u;
     // first stage, parts 1 and 2 for one displacement pattern (sa, sb = displacement of the combo's
     // first and second piece; compile-time constants at every call): 16 hashes, 16 LDS reads in
     // flight, three bit tests per window, verdicts funnelled into one register
@@ -821,11 +821,9 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     for (int v = 0; v < NV; ++v) {
       const int cost = (VD1[v] < 0 ? -VD1[v] : VD1[v]) + (VD2[v] < 0 ? -VD2[v] : VD2[v]);
       rems[v] = 0;
-      // Pieces next to each other can only be pulled apart by characters inserted between them:
-      // the left one then sits further left (negative displacement).  A positive displacement
-      // would need a deleted character, which belongs to one of the two pieces.
-      const bool possible = !((VD1[v] > 0 && (eadj & 2u)) || (VD2[v] > 0 && (eadj & 1u)));
-      if (!EDITS || (cost <= a.edits && possible)) rems[v] = tests(VD1[v] + VD2[v], VD1[v]);
+      // which (combo, displacement) pairs are needed is decided on the host (edit_cover): a set
+      // cover over all placements of <= k edits, 34 of the 130 pairs for k = 2
+      if (!EDITS || (cost <= a.edits && ((evar >> v) & 1u))) rems[v] = tests(VD1[v] + VD2[v], VD1[v]);
     }
     // part 3: compaction, one survivor per lane and round (ballot + mbcnt give the queue slots)
 #pragma unroll 1
@@ -919,6 +917,59 @@ static uint64_t binom(int n, int r) {
   uint64_t v = 1;
   for (int i = 1; i <= r; ++i) v = v * (n - r + i) / i;
   return v;
+}
+
+// Which (combo, displacement pattern) pairs the edit-distance first stage has to test.
+// Every way of placing <= k edits on the m = k+3 pieces of the seeded window (a substitution, an
+// inserted or a deleted character inside a piece -- the piece is then unusable -- or characters
+// inserted between two pieces) leaves >= 3 clean pieces, each displaced by the indels to its
+// right.  A placement is found if one of its clean triples is tested under its displacement
+// pattern (d1 = second minus third piece, d2 = first minus second).  Greedy set cover over all
+// placements: 34 pairs for k = 2 (of 85 that can occur, 130 in all), 5 for k = 1.
+static void edit_cover(int k, int m, const std::vector<std::array<int, 4>> &combos, uint32_t *evar) {
+  static const int VD1[13] = {0, 0, 0, 1, -1, 0, 0, 2, -2, 1, 1, -1, -1};
+  static const int VD2[13] = {0, 1, -1, 0, 0, 2, -2, 0, 0, 1, -1, 1, -1};
+  const int C = (int)combos.size();
+  struct Loc { int kind, x; };                         // 0 substitution, 1 insertion, 2 deletion inside piece x; 3 insertion after piece x
+  std::vector<Loc> locs;
+  for (int kind = 0; kind < 3; ++kind) for (int q = 0; q < m; ++q) locs.push_back({kind, q});
+  for (int b = 0; b + 1 < m; ++b) locs.push_back({3, b});
+  std::vector<std::vector<int>> scen(1);               // placements as lists of location indices (with repetition)
+  for (int i = 0; i < (int)locs.size(); ++i) {
+    scen.push_back({i});
+    if (k >= 2) for (int j = i; j < (int)locs.size(); ++j) scen.push_back({i, j});
+  }
+  std::vector<std::vector<uint8_t>> covers(scen.size(), std::vector<uint8_t>((size_t)C * 13, 0));
+  for (size_t si = 0; si < scen.size(); ++si) {
+    std::vector<int> shift(m, 0);
+    std::vector<bool> dirty(m, false);
+    for (int li : scen[si]) {
+      const Loc &l = locs[li];
+      if (l.kind < 3) dirty[l.x] = true;
+      if (l.kind == 1) for (int q = 0; q < l.x; ++q) --shift[q];          // extra stream character: pieces to the left sit further left
+      if (l.kind == 2) for (int q = 0; q < l.x; ++q) ++shift[q];
+      if (l.kind == 3) for (int q = 0; q <= l.x; ++q) --shift[q];
+    }
+    for (int c = 0; c < C; ++c) {
+      const int pa = combos[c][0], pb = combos[c][1], pc = combos[c][2];
+      if (dirty[pa] || dirty[pb] || dirty[pc]) continue;
+      const int d1 = shift[pb] - shift[pc], d2 = shift[pa] - shift[pb];
+      for (int v = 0; v < 13; ++v) if (VD1[v] == d1 && VD2[v] == d2) covers[si][(size_t)c * 13 + v] = 1;
+    }
+  }
+  for (int c = 0; c < C; ++c) evar[c] = 0;
+  std::vector<bool> done(scen.size(), false);
+  for (;;) {
+    int best = -1, bestn = 0;
+    for (int u = 0; u < C * 13; ++u) {
+      int cnt = 0;
+      for (size_t si = 0; si < scen.size(); ++si) if (!done[si] && covers[si][u]) ++cnt;
+      if (cnt > bestn) { bestn = cnt; best = u; }
+    }
+    if (best < 0) break;
+    evar[best / 13] |= 1u << (best % 13);
+    for (size_t si = 0; si < scen.size(); ++si) if (covers[si][best]) done[si] = true;
+  }
 }
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
@@ -1119,8 +1170,8 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   for (int c = 0; c < d->ncombos; ++c) {              // byte masks of the combo's first and second piece (edits: displaced pieces)
     d->emask_a[c] = t.r >= 3 && t.combos[c][0] < 4 ? 0xffu << (8 * t.combos[c][0]) : 0u;
     d->emask_b[c] = t.r >= 3 && t.combos[c][1] < 4 ? 0xffu << (8 * t.combos[c][1]) : 0u;
-    d->eadj[c] = t.r >= 3 ? ((t.combos[c][1] == t.combos[c][0] + 1 ? 1u : 0u) | (t.combos[c][2] == t.combos[c][1] + 1 ? 2u : 0u)) : 0u;
   }
+  if (t.edits) edit_cover(t.edits, t.k + t.r, t.combos, d->evar);
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
@@ -1176,7 +1227,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
   a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code;
   a.edits = d.edits; a.maxlen = d.maxlen;
-  memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); memcpy(a.eadj, d.eadj, sizeof(a.eadj)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
+  memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); memcpy(a.evar, d.evar, sizeof(a.evar)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
