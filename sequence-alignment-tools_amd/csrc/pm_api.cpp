@@ -1288,11 +1288,20 @@ extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, si
       rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
     }
     if (rc) return rc;
-    cands.resize(cnt);
-    if (cnt) HIP_TRY(h, hipMemcpy(cands.data(), h->d_cands, cnt * sizeof(pm_hit), hipMemcpyDeviceToHost));
     std::vector<pm_hit> outv;
-    rc = finalize_into(h, cands.data(), cnt, end, end >= h->n, outv);
-    if (rc) return rc;
+    if (h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && h->pats.size() < ((size_t)1 << 22)) {
+      // clusters and their DPs on the device (pm_cluster_dp); only what it hands back goes through the host stage
+      outv.resize(cnt + h->carry.size() + 16);
+      size_t nout = 0;
+      rc = pm_finalize_device(h, nullptr, 0, end, end >= h->n ? PM_FINALIZE_LAST : 0, outv.data(), outv.size(), &nout);
+      if (rc) return rc;
+      outv.resize(nout);
+    } else {
+      cands.resize(cnt);
+      if (cnt) HIP_TRY(h, hipMemcpy(cands.data(), h->d_cands, cnt * sizeof(pm_hit), hipMemcpyDeviceToHost));
+      rc = finalize_into(h, cands.data(), cnt, end, end >= h->n, outv);
+      if (rc) return rc;
+    }
     std::sort(outv.begin(), outv.end(), by_end_pid);
     if (h->ready_pos == h->ready.size()) { h->ready.clear(); h->ready_pos = 0; }
     h->ready.insert(h->ready.end(), outv.begin(), outv.end());
