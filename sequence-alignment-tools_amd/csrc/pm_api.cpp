@@ -771,11 +771,6 @@ int fetch_windows(pm_handle *h, std::vector<Window> &wins) {
     }
     if (h->d_woutcap < (size_t)total) {
       if (h->d_wout) (void)hipFree(h->d_wout);
-  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id};
-  for (void *q : fw) if (q) (void)hipFree(q);
-  if (h->h_fcounts) (void)hipHostFree(h->h_fcounts);
-  h->d_keys = h->d_keys_alt = nullptr; h->d_ctemp = nullptr; h->d_fout = h->d_fleft = nullptr; h->d_fcounts = nullptr;
-  h->h_fcounts = nullptr; h->d_fpat_len = nullptr; h->d_fpat_id = nullptr; h->ckeys_cap = 0; h->ctemp_bytes = 0;
       h->d_woutcap = (size_t)total * 2;
       HIP_TRY(h, hipMalloc((void **)&h->d_wout, h->d_woutcap));
     }

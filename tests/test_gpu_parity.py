@@ -423,3 +423,27 @@ def test_edit_distance_seed_plan(seed):
                     assert got == want, (seed, tbl is None, k, sem, chunk, len(got), len(want))
                 total += len(want)
     assert total > 0
+
+
+def test_edit_distance_device_text_with_repeat_clusters():
+    """Stream only in HBM (pm_init_device) + tandem repeats: the long repeat clusters that
+    pm_cluster_dp hands back go through the host stage, whose window gather must not disturb the
+    device results waiting to be copied (regression: it once freed the sort workspace)."""
+    import torch
+    rng = np.random.default_rng(77)
+    ents = synth.make_entries(rng, 3, 20000, n_runs=2, repeats=True, short=True)
+    pats = synth.make_patterns(rng, ents, 300, length=20, planted=0.3)
+    allp = [p for p in pats + [synth.revcomp(p) for p in pats] if set(p) <= set("ACGT") and len(p) >= 20]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    dev = torch.from_numpy(codes).to("cuda:0")
+    want = O.sorted_tuples(O.find_all(O.Text(codes, table), allp, engine=5, k=2, indels=True))
+    for chunk in (1 << 26, 7000):
+        pm = sat_amd.PatternMatch(k=2, indels=True)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init_device(dev.data_ptr(), dev.numel(), table, keepalive=dev)
+        assert pm.selected() == (sat_amd.SEM_FILTER_BITVEC, sat_amd.KERNEL_SEED)
+        got = sat_amd.sorted_tuples(pm.find_all(chunk=chunk))
+        pm.close()
+        assert got == want and len(want) > 0, (chunk, len(got), len(want))
