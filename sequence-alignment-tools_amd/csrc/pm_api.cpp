@@ -494,8 +494,11 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   {
     // per pattern tile: scan kernel -> seed records in d_ext, verify kernel -> candidates in d_cands
     // ~1 seed record per 8 bases at 200k patterns (key matches that pass the four-base-word test)
-    if (!h->d_seeds) {
-      if (h->seed_cap == 0) h->seed_cap = std::max<size_t>((size_t)(h->n / 6), (size_t)1 << 20);
+    // (sized for the range being scanned; a denser stream overflows once and the buffer grows)
+    const size_t want_seeds = (size_t)((end - begin) / 6) + ((size_t)1 << 20);
+    if (!h->d_seeds || h->seed_cap < want_seeds) {
+      if (h->d_seeds) { (void)hipFree(h->d_seeds); h->d_seeds = nullptr; }
+      h->seed_cap = std::max(h->seed_cap, want_seeds);
       HIP_TRY(h, hipMalloc((void **)&h->d_seeds, h->seed_cap * sizeof(uint64_t)));
     }
     if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, (1 + 256) * sizeof(unsigned long long)));

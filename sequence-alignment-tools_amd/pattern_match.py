@@ -51,7 +51,10 @@ def build_library(force=False):
 
 
 def load_library():
-    """Load csrc/libpm_gpu.so.  No fallback: a missing library is an error."""
+    """Load csrc/libpm_gpu.so.  No fallback: a missing library is an error.
+
+    Processes that also use PyTorch on the GPU should import torch first: torch ships its own HIP
+    runtime, and whichever runtime is loaded first serves the process."""
     global _LIB
     if _LIB is None:
         path = library_path()

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# PyTorch bundles its own HIP runtime: it has to be loaded before libpm_gpu.so pulls in the system one,
+# or torch finds no GPU later in the same process (tests that allocate the stream with torch).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
