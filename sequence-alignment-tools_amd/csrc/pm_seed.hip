@@ -816,23 +816,24 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     constexpr int NV = EDITS ? 13 : 1;
     constexpr int VD1[13] = {0, 0, 0, 1, -1, 0, 0, 2, -2, 1, 1, -1, -1};
     constexpr int VD2[13] = {0, 1, -1, 0, 0, 2, -2, 0, 0, 1, -1, 1, -1};
-    uint32_t rems[NV];
+    uint32_t rems2[(NV + 1) / 2];                                  // two 16-bit survivor masks per register
+#pragma unroll
+    for (int v = 0; v < (NV + 1) / 2; ++v) rems2[v] = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int cost = (VD1[v] < 0 ? -VD1[v] : VD1[v]) + (VD2[v] < 0 ? -VD2[v] : VD2[v]);
-      rems[v] = 0;
       // which (combo, displacement) pairs are needed is decided on the host (edit_cover): a set
       // cover over all placements of <= k edits, 34 of the 130 pairs for k = 2
-      if (!EDITS || (cost <= a.edits && ((evar >> v) & 1u))) rems[v] = tests(VD1[v] + VD2[v], VD1[v]);
+      if (!EDITS || (cost <= a.edits && ((evar >> v) & 1u))) rems2[v >> 1] |= tests(VD1[v] + VD2[v], VD1[v]) << (16 * (v & 1));
     }
     // part 3: compaction, one survivor per lane and round (ballot + mbcnt give the queue slots)
 #pragma unroll 1
     for (int v = 0; v < NV; ++v) {
-      uint32_t rem = rems[0];
+      uint32_t rem = rems2[0] & 0xffffu;
       int sa = 0, sb = 0;
       if (EDITS) {
 #pragma unroll
-        for (int t = 1; t < NV; ++t) if (v == t) { rem = rems[t]; sa = VD1[t] + VD2[t]; sb = VD1[t]; }
+        for (int t = 1; t < NV; ++t) if (v == t) { rem = (rems2[t >> 1] >> (16 * (t & 1))) & 0xffffu; sa = VD1[t] + VD2[t]; sb = VD1[t]; }
       }
       for (;;) {
         const unsigned long long bal = __ballot(rem != 0);
