@@ -34,6 +34,7 @@ import sat_amd  # noqa: E402
 TABLE = b"ACGT\n"           # compress_seq -n true codes: A0 C1 G2 T3 EOS4 (compress_seq.cc:704-719)
 EOS = 4
 HALO = 256
+GUARD = 1 << 16          # guard band of a shard: chains of candidates shorter than this are decided locally
 BLOCK = 1 << 24             # generation granule: block b of the global stream is seeded with (seed, b)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 32-bit integer lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
@@ -221,8 +222,11 @@ def main():
     total = args.db_bases * world if args.scaling == "weak" else args.db_bases
     shard = (total + world - 1) // world
     lo, hi = rank * shard, min(total, (rank + 1) * shard)
-    glo = max(0, lo - HALO)
-    ghi = min(total, hi + HALO)          # right halo: seed extensions (-k) read up to len+k bytes past a shard's end
+    # a shard holds its own bytes, a guard band either side (filter_bitvec chains that straddle a shard
+    # edge are decided by the shard that owns the hit, pm_finalize_device_owned) and a halo of text
+    # the windows / seed extensions of the outermost candidates read
+    glo = max(0, lo - GUARD - HALO)
+    ghi = min(total, hi + GUARD + HALO)
     stream = gen_stream(glo, ghi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev)
     n_bases_total = total - (args.entries * (world if args.scaling == "weak" else 1) + 1)
     if rank == 0:
@@ -254,14 +258,18 @@ def main():
     final_hits = [0]
     cand_count = [0]
 
-    out_buf = np.empty(1 << 24, dtype=sat_amd.HIT_DTYPE)          # host landing zone for final hits
+    # host landing zone for final hits (pinned: the copy out of HBM is part of every step)
+    out_pin = torch.empty((1 << 24) * 16, dtype=torch.uint8, pin_memory=True)
+    out_buf = out_pin.numpy().view(sat_amd.HIT_DTYPE)
+    # filter_bitvec: every rank clusters and verifies what it owns; only final hits travel
+    own_path = world > 1 and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC
+    g_lo = 0 if glo == 0 else begin - GUARD
+    g_hi = stream.numel() if ghi == total else end + GUARD
+    all_pin = torch.empty((1 << 24) * 2 * (world if own_path else 1), dtype=torch.int64, pin_memory=True) if rank == 0 and own_path else None
     dev_final = [True]                                              # GPU clustering available for this option set?
 
     def finalize_rank0(ptr, cnt, scanned_to):
         """records in HBM -> final hits on the host of rank 0"""
-        if world > 1 and args.indels and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC:
-            # the clusters' DPs read stream text around every candidate; rank 0 holds only its own shard
-            raise SystemExit("bench.py --gpus>1: filter_bitvec with edits verifies against stream text, which rank 0 does not hold (DESIGN.md 5)")
         if dev_final[0]:
             try:
                 return pm.finalize_device(scanned_to, last=True, sort=False, d_cands=ptr, n=cnt, out=out_buf)
@@ -277,7 +285,39 @@ def main():
         pm.reset()
         return pm.finalize(cands, scanned_to, last=True, sort=False)
 
+    def step_owned():
+        pm.scan_async(g_lo, g_hi)
+        ncand = pm.scan_wait()
+        ms, _ = pm.last_kernel_time()
+        kernel_ms.append(ms)
+        mine_hits = pm.finalize_device(0, sort=False, out=out_buf, owned=(begin, end, g_lo, None if ghi == total else g_hi))
+        cnt = mine_hits.size
+        # the path's one exchange: final hit records to rank 0 over xGMI
+        mine = torch.tensor([cnt], dtype=torch.int64, device=cdev)
+        clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(clist, mine)
+        cl = [int(x.item()) for x in clist]
+        mx = max(max(cl), 1)
+        pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)
+        if cnt:
+            pad[:cnt * 2].copy_(out_pin[:cnt * 16].view(torch.int64), non_blocking=True)
+        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, gathered, dst=0)
+        if rank == 0:
+            at = 0
+            for r in range(world):
+                a = gathered[r][:cl[r] * 2].view(-1, 2)
+                a[:, 0] += max(0, r * shard - GUARD - HALO)            # local -> global stream index
+                all_pin[at:at + cl[r] * 2].copy_(a.reshape(-1), non_blocking=True)   # shards are in stream order
+                at += cl[r] * 2
+            torch.cuda.synchronize()
+            cand_count[0] = at // 2
+            final_hits[0] = at // 2
+        return ncand
+
     def step():
+        if own_path:
+            return step_owned()
         pm.scan_async(begin, end)
         ncand = pm.scan_wait()
         ms, _ = pm.last_kernel_time()
@@ -302,7 +342,7 @@ def main():
             parts = []
             for r in range(world):
                 a = gathered[r][:cl[r] * 2].view(-1, 2).to(dev)
-                a[:, 0] += max(0, r * shard - HALO)                  # local -> global stream index
+                a[:, 0] += max(0, r * shard - GUARD - HALO)          # local -> global stream index
                 parts.append(a)
             allrec = torch.cat(parts).contiguous()
             torch.cuda.current_stream().synchronize()

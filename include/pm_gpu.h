@@ -8,8 +8,10 @@
  * A handle is owned by one host thread (the reference is single-threaded).
  *
  * Data flow:  pm_create -> pm_add_pattern xN -> pm_init[_device] -> pm_scan ... -> pm_destroy
- * Multi-GPU:  each rank pm_scan_candidates() on its shard of the stream, candidate records are
- *             gathered (RCCL), one rank pm_finalize()s them in stream order.
+ * Multi-GPU:  each rank pm_scan_candidates() on its shard of the stream; filter_bitvec option sets
+ *             then pm_finalize_device_owned() on the same rank and the final hits are gathered
+ *             (RCCL) in rank order; for the others the candidate records are gathered and one
+ *             rank pm_finalize()s them in stream order.
  */
 #ifndef PM_GPU_H
 #define PM_GPU_H
@@ -142,6 +144,18 @@ int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to,
  * (PM_E_UNSUPPORTED otherwise: use pm_finalize). */
 int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                        pm_hit *out, size_t cap, size_t *n_out);
+
+/* One shard of a position-sharded scan (the reference has no such call, its scan is
+ * one serial pass -- filter_bitvec.cc:88-177 over the whole stream).  The records (d_cands, or
+ * NULL = the last pm_scan_candidates) must hold every candidate with guard_lo < end <= guard_hi;
+ * the call reports the final hits with own_lo < end <= own_hi.  Because a cluster's hit ends between
+ * its first and last candidate, the shards' outputs concatenate to exactly the single-scan result
+ * as long as no same-pattern chain reaches from a guard edge into the owned range (a tandem repeat
+ * longer than the guard band): that case returns PM_E_UNSUPPORTED.  guard_lo <= 0 and guard_hi ==
+ * INT64_MAX declare the true start / end of the stream (nothing can be hidden beyond them).  Only
+ * for the option sets pm_finalize_device supports; implies PM_FINALIZE_LAST. */
+int pm_finalize_device_owned(pm_handle *h, const void *d_cands, size_t n, int64_t own_lo, int64_t own_hi,
+                             int64_t guard_lo, int64_t guard_hi, int flags, pm_hit *out, size_t cap, size_t *n_out);
 
 /* The caller's per-hit re-alignment (primer_match.cc:1135-1151, pcr_match.cc:1108-1127):
  * exact_alignment::align (pattern_alignment.cc:29-43) for k == 0, otherwise

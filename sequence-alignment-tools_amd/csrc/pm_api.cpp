@@ -549,8 +549,8 @@ static int ensure_sort_workspace(pm_handle *h, size_t n, bool with_out) {
     HIP_TRY(h, hipMalloc((void **)&h->d_fleft, h->ckeys_cap * sizeof(pm_hit)));
   }
   if (!h->d_fcounts) {
-    HIP_TRY(h, hipMalloc((void **)&h->d_fcounts, 2 * sizeof(unsigned long long)));
-    HIP_TRY(h, hipHostMalloc((void **)&h->h_fcounts, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(h, hipMalloc((void **)&h->d_fcounts, 4 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipHostMalloc((void **)&h->h_fcounts, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   return PM_OK;
 }
@@ -1084,8 +1084,31 @@ extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
 // d_cands == NULL means "the records of the last pm_scan_candidates".  Final hits are copied to
 // `out` (host).  The few clusters the device cannot decide (still growing at scanned_to, or
 // starting inside the first L characters) go through the host stage.
+static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
+                                const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out);
+
 extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                                   pm_hit *out, size_t cap, size_t *n_out) {
+  const OwnedRange all = {0, 0, 0, 0, 0};
+  return finalize_device_impl(h, d_cands, n, scanned_to, flags, all, out, cap, n_out);
+}
+
+// One shard of a position-sharded scan: the records hold every candidate that ends
+// in (guard_lo, guard_hi] and this call reports the hits that end in (own_lo, own_hi], so the shards'
+// outputs concatenate to the single-scan result without a merge stage and each shard's cluster DPs
+// read the text the shard itself holds.  guard_lo <= 0 / guard_hi == INT64_MAX: the stream really
+// starts / ends there.  A same-pattern chain of candidates that reaches from a guard edge into the
+// owned range (a tandem repeat longer than the guard band) cannot be decided here: PM_E_UNSUPPORTED.
+extern "C" int pm_finalize_device_owned(pm_handle *h, const void *d_cands, size_t n, int64_t own_lo, int64_t own_hi,
+                                        int64_t guard_lo, int64_t guard_hi, int flags, pm_hit *out, size_t cap, size_t *n_out) {
+  if (!(guard_lo <= own_lo && own_lo <= own_hi && own_hi <= guard_hi))
+    return fail(h, PM_E_INVALID, "pm_finalize_device_owned: need guard_lo <= own_lo <= own_hi <= guard_hi");
+  const OwnedRange own = {own_lo, own_hi, guard_lo, guard_hi, 1};
+  return finalize_device_impl(h, d_cands, n, guard_hi == INT64_MAX ? h->n : guard_hi, flags | PM_FINALIZE_LAST, own, out, cap, n_out);
+}
+
+static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
+                                const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out) {
   if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_finalize_device: handle not initialised");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const pm_hit *src = d_cands ? (const pm_hit *)d_cands : h->d_cands;
@@ -1103,6 +1126,7 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
     if (n > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
     if (n) HIP_TRY(h, hipMemcpyAsync(out, src, n * sizeof(pm_hit), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (own.on) n = (size_t)(std::remove_if(out, out + n, [&](const pm_hit &x) { return !(x.end > own.own_lo && x.end <= own.own_hi); }) - out);
     if (flags & PM_FINALIZE_SORTED) std::sort(out, out + n, by_end_pid);
     if (n_out) *n_out = n;
     return PM_OK;
@@ -1141,14 +1165,17 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
   const double tfd0 = now_ms();
   if (cluster_dp)
     HIP_TRY(h, cluster_dp_device(src, n, h->cfg.k, true, scanned_to, last, h->d_text, h->n, h->eos_code, h->d_dp_codes, h->d_fpat_len,
-                                 h->d_dp_esb, h->d_dp_eeb, h->d_fpat_id, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes,
+                                 h->d_dp_esb, h->d_dp_eeb, h->d_fpat_id, own, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes,
                                  h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
   else
-  HIP_TRY(h, cluster_device(src, n, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, h->d_keys, h->d_keys_alt,
+  HIP_TRY(h, cluster_device(src, n, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, own, h->d_keys, h->d_keys_alt,
                             h->d_ctemp, h->ctemp_bytes, h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  h->h_fcounts[2] = 0;
+  HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, (n ? 3 : 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const size_t nfin = (size_t)h->h_fcounts[0], nleft = (size_t)h->h_fcounts[1];
+  if (own.on && h->h_fcounts[2])
+    return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device_owned: a chain of candidates reaches from the guard edge into the owned range (repeat longer than the guard band)");
   const double tfd1 = now_ms();
   if (nleft) {
     const size_t at = hostpart.size();
@@ -1159,6 +1186,7 @@ extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, i
   if (!hostpart.empty()) {
     int rc = finalize_into(h, hostpart.data(), hostpart.size(), scanned_to, last, extra);
     if (rc) return rc;
+    if (own.on) extra.erase(std::remove_if(extra.begin(), extra.end(), [&](const pm_hit &x) { return !(x.end > own.own_lo && x.end <= own.own_hi); }), extra.end());
   }
   if (nfin + extra.size() > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
   if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));

@@ -27,8 +27,22 @@ __global__ void pm_cluster_pack(const pm_hit *in, size_t n, uint64_t *keys) {
   keys[i] = ((uint64_t)h.pid << 42) | (((uint64_t)h.end & 0xffffffffffull) << 2) | (uint64_t)(h.k & 3u);
 }
 
+// Position-sharded scans (OwnedRange, pm_internal.h): a chain the guard edge may have cut is an
+// error when its hit could land in the owned range, and simply another shard's otherwise.
+// Returns true when the chain [first, last] is to be processed here.
+__device__ __forceinline__ bool chain_owned(const OwnedRange &own, int64_t first, int64_t last, int win, unsigned long long *cut_count) {
+  if (!own.on) return true;
+  const bool cut_l = own.guard_lo > 0 && first - win <= own.guard_lo;     // a predecessor may hide at <= guard_lo
+  const bool cut_r = last > own.guard_hi - win;                           // a successor may follow guard_hi
+  if ((cut_l && last > own.own_lo) || (cut_r && first <= own.own_hi)) { atomicAdd(cut_count, 1ull); return false; }
+  return last > own.own_lo && first <= own.own_hi;                        // the hit ends inside [first, last]
+}
+__device__ __forceinline__ bool hit_owned(const OwnedRange &own, int64_t end) {
+  return !own.on || (end > own.own_lo && end <= own.own_hi);
+}
+
 __global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64_t scanned_to, int last,
-                                  const uint8_t *pat_len, const uint32_t *pat_id,
+                                  const uint8_t *pat_len, const uint32_t *pat_id, OwnedRange own,
                                   pm_hit *out, unsigned long long *out_count,
                                   pm_hit *left, unsigned long long *left_count) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -51,6 +65,7 @@ __global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64
     if (lv < best) { best = lv; best_end = ne; }
     prev = ne;
   }
+  if (!chain_owned(own, end, prev, win, out_count + 2)) return;
   const bool incomplete = !last && scanned_to < prev + win;        // filter_bitvec.cc:118-121
   const bool needs_dp = end < (int64_t)pat_len[pid - 1];            // window not fully inside the stream
   if (incomplete || needs_dp) {
@@ -61,7 +76,7 @@ __global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64
       h.aux[0] = h.aux[1] = h.aux[2] = 0;
       left[o + (t - i)] = h;
     }
-  } else {
+  } else if (hit_owned(own, best_end)) {
     const unsigned long long o = atomicAdd(out_count, 1ull);
     pm_hit h;
     h.pid = pat_id[pid - 1]; h.end = best_end; h.k = (uint8_t)best; h.aux[0] = h.aux[1] = h.aux[2] = 0;
@@ -199,7 +214,7 @@ __device__ bool device_editdist(const uint8_t *text, int64_t n, int64_t end, int
 __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels, int64_t scanned_to, int last,
                               const uint8_t *text, int64_t ntext, int eos,
                               const uint8_t *pat_codes, const uint8_t *pat_len, const int32_t *esb, const int32_t *eeb,
-                              const uint32_t *pat_id, pm_hit *out, unsigned long long *out_count,
+                              const uint32_t *pat_id, OwnedRange own, pm_hit *out, unsigned long long *out_count,
                               pm_hit *left, unsigned long long *left_count) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -220,6 +235,7 @@ __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels,
     if ((uint32_t)(nk >> 42) != pid || ne - prev > win) break;
     prev = ne;
   }
+  if (!chain_owned(own, end, prev, win, out_count + 2)) return;
   const int L = pat_len[pid - 1];
   const bool incomplete = !last && scanned_to < prev + win;        // :118-121
   if (incomplete || prev - end > DP_MAXDELTA || L > DP_MAXL || k > 3) {   // host stage: may still grow / long repeat cluster
@@ -234,7 +250,8 @@ __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels,
     return;
   }
   int64_t rend = 0; int rval = 0;
-  if (device_editdist(text, ntext, end, prev, pat_codes + (size_t)(pid - 1) * 32, L, esb[pid - 1], eeb[pid - 1], k, indels != 0, eos, &rend, &rval)) {
+  if (device_editdist(text, ntext, end, prev, pat_codes + (size_t)(pid - 1) * 32, L, esb[pid - 1], eeb[pid - 1], k, indels != 0, eos, &rend, &rval) &&
+      hit_owned(own, rend)) {
     const unsigned long long o = atomicAdd(out_count, 1ull);
     pm_hit h;
     h.pid = pat_id[pid - 1]; h.end = rend; h.k = (uint8_t)rval; h.aux[0] = h.aux[1] = h.aux[2] = 0;
@@ -245,13 +262,14 @@ __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels,
 }  // namespace
 
 // Clustering + one DP per cluster for filter_bitvec with edits.  Records in any order (duplicates and
-// holes allowed); finals to d_out / d_counts[0], records the host stage must look at to d_left / d_counts[1].
+// holes allowed); finals to d_out / d_counts[0], records the host stage must look at to d_left / d_counts[1],
+// chains cut by the guard edge of an owned range counted in d_counts[2].
 hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, int64_t scanned_to, bool last,
                              const uint8_t *d_text, int64_t ntext, int eos_code,
                              const uint8_t *d_pat_codes, const uint8_t *d_pat_len, const int32_t *d_esb, const int32_t *d_eeb,
-                             const uint32_t *d_pat_id, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                             const uint32_t *d_pat_id, const OwnedRange &own, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                              pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), st);
+  hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), st);
   if (e != hipSuccess || n == 0) return e;
   const int threads = 256;
   const unsigned blocks = (unsigned)((n + threads - 1) / threads);
@@ -259,7 +277,7 @@ hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, i
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(pm_cluster_dp, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, k, indels ? 1 : 0, scanned_to, last ? 1 : 0,
-                     d_text, ntext, eos_code, d_pat_codes, d_pat_len, d_esb, d_eeb, d_pat_id, d_out, d_counts, d_left, d_counts + 1);
+                     d_text, ntext, eos_code, d_pat_codes, d_pat_len, d_esb, d_eeb, d_pat_id, own, d_out, d_counts, d_left, d_counts + 1);
   return hipGetLastError();
 }
 
@@ -285,10 +303,10 @@ size_t cluster_temp_bytes(size_t n) {
 }
 
 hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_to, bool last,
-                          const uint8_t *d_pat_len, const uint32_t *d_pat_id,
+                          const uint8_t *d_pat_len, const uint32_t *d_pat_id, const OwnedRange &own,
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), st);
+  hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), st);
   if (e != hipSuccess || n == 0) return e;
   const int threads = 256;
   const unsigned blocks = (unsigned)((n + threads - 1) / threads);
@@ -296,7 +314,7 @@ hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_t
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(pm_cluster_reduce, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, 2 * k + 1, scanned_to, last ? 1 : 0,
-                     d_pat_len, d_pat_id, d_out, d_counts, d_left, d_counts + 1);
+                     d_pat_len, d_pat_id, own, d_out, d_counts, d_left, d_counts + 1);
   return hipGetLastError();
 }
 

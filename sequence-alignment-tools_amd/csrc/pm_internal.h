@@ -79,9 +79,14 @@ hipError_t gather_windows(const uint8_t *d_text, int64_t n, const int64_t *d_sta
 
 
 // ---- device clustering for -K filter_bitvec (pm_cluster.hip) ----------------------------------
+// Position sharding: the records cover ends in (guard_lo, guard_hi]; this shard
+// reports the clusters whose hit ends in (own_lo, own_hi].  guard_lo <= 0 / guard_hi = INT64_MAX
+// mean the true start / end of the stream.
+struct OwnedRange { int64_t own_lo, own_hi, guard_lo, guard_hi; int on; };
+
 size_t cluster_temp_bytes(size_t n);
 hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_to, bool last,
-                          const uint8_t *d_pat_len, const uint32_t *d_pat_id,
+                          const uint8_t *d_pat_len, const uint32_t *d_pat_id, const OwnedRange &own,
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
 
@@ -96,7 +101,7 @@ hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t
 hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, int64_t scanned_to, bool last,
                              const uint8_t *d_text, int64_t ntext, int eos_code,
                              const uint8_t *d_pat_codes, const uint8_t *d_pat_len, const int32_t *d_esb, const int32_t *d_eeb,
-                             const uint32_t *d_pat_id, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
+                             const uint32_t *d_pat_id, const OwnedRange &own, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                              pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
 
 // ---- seed extension DP on the GPU (pm_extend.hip) ---------------------------------------------

@@ -20,7 +20,7 @@ PM_E_OVERFLOW = -5
 ABI_SYMBOLS = [
     "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_candidates",
     "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
-    "pm_finalize_device", "pm_align_hits", "pm_align_hits_text",
+    "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
 ]
@@ -81,6 +81,8 @@ def load_library():
         L.pm_set_capacity.argtypes = [C.c_void_p, C.c_size_t]
         L.pm_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_finalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.pm_finalize_device_owned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                               C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_align_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.pm_align_hits_text.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.pm_reset.argtypes = [C.c_void_p]
@@ -270,13 +272,21 @@ class PatternMatch:
                                         out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
         return out[:n_out.value]
 
-    def finalize_device(self, scanned_to, last=True, sort=True, d_cands=None, n=0, out=None):
+    def finalize_device(self, scanned_to, last=True, sort=True, d_cands=None, n=0, out=None, owned=None):
         """GPU clustering of the records of the last scan (or of `d_cands`, a device pointer);
-        returns the final hits (host array).  Raises PmError(-2) where only the host stage applies."""
+        returns the final hits (host array).  Raises PmError(-2) where only the host stage applies.
+        owned=(own_lo, own_hi, guard_lo, guard_hi): this call is one shard of a position-sharded
+        scan (pm_finalize_device_owned); guard_hi=None declares the true end of the stream."""
         if out is None:
             cap = max(n if d_cands else self.candidates_device()[1], 1) + 1024
             out = np.empty(cap, dtype=HIT_DTYPE)
         n_out = C.c_size_t()
+        if owned is not None:
+            own_lo, own_hi, guard_lo, guard_hi = owned
+            self._check(self._L.pm_finalize_device_owned(self._h, C.c_void_p(d_cands or 0), n, own_lo, own_hi, guard_lo,
+                                                         (1 << 63) - 1 if guard_hi is None else guard_hi, 2 if sort else 0,
+                                                         out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+            return out[:n_out.value]
         self._check(self._L.pm_finalize_device(self._h, C.c_void_p(d_cands or 0), n, scanned_to,
                                                (1 if last else 0) | (2 if sort else 0),
                                                out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))

@@ -247,6 +247,66 @@ def test_device_cluster_dp_equals_host_stage(case):
         pm.close()
 
 
+def _sharded_owned(codes, table, pats, k, indels, shards, guard, halo=64):
+    """Every shard builds its own engine over its slice of the stream (+ guard band + halo), scans
+    the guard range and reports what it owns -- bench.py's multi-GPU data path, ranks run in turn."""
+    n = codes.size
+    size = (n + shards - 1) // shards
+    out = []
+    for r in range(shards):
+        lo, hi = r * size, min(n, (r + 1) * size)
+        glo, ghi = max(0, lo - guard - halo), min(n, hi + guard + halo)
+        local = np.ascontiguousarray(codes[glo:ghi])
+        pm = sat_amd.PatternMatch(k=k, indels=indels, semantics=sat_amd.SEM_FILTER_BITVEC,
+                                  kernel=sat_amd.KERNEL_SEED if indels else sat_amd.KERNEL_AUTO)
+        for i, p in enumerate(pats):
+            pm.add_pattern(p, i + 1)
+        pm.init(local, table)
+        g_lo = 0 if glo == 0 else lo - guard - glo
+        g_hi = ghi - glo if ghi == n else hi + guard - glo
+        pm.scan_candidates(g_lo, g_hi, to_host=False)
+        hits = pm.finalize_device(0, owned=(lo - glo, hi - glo, g_lo, None if ghi == n else g_hi)).copy()
+        hits["end"] += glo
+        out.append(hits)
+        pm.close()
+    return out
+
+
+@pytest.mark.parametrize("case", ["varlen_repeats", "dense_indels"])
+@pytest.mark.parametrize("indels", [False, True])
+def test_position_sharded_finalize_equals_single_scan(case, indels):
+    """shards that finalize their own clusters (pm_finalize_device_owned) concatenate
+    to the single-scan filter_bitvec result -- no candidate gather, no merge, text stays local."""
+    c, codes, table, allp = load([p for p in CASES if case in p][0])
+    pats = [p for p in allp if 20 <= len(p) <= 32] if indels else allp
+    if len(pats) < 4:
+        pytest.skip("patterns of this fixture are shorter than 20")
+    for k in (1, 2):
+        want = O.sorted_tuples(O.find_all(O.Text(codes, table), pats, engine=5, k=k, indels=indels))
+        for shards in (2, 3, 7):
+            parts = _sharded_owned(codes, table, pats, k, indels, shards, guard=512)
+            got = [tuple(int(v) for v in (h["end"], h["pid"], h["k"])) for part in parts for h in part]
+            assert sorted(got) == want and len(want) > 0, (case, indels, k, shards, len(got), len(want))
+
+
+def test_position_sharded_finalize_refuses_cut_chain():
+    """A tandem repeat longer than the guard band across a shard edge: the chain's fate is not
+    decidable inside the shard, and the call says so instead of reporting a different hit."""
+    rng = np.random.default_rng(5)
+    left = "".join(rng.choice(list("ACGT"), size=700).tolist())
+    right = "".join(rng.choice(list("ACGT"), size=700).tolist())
+    ents = [left + "A" * 400 + right]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    pats = ["A" * 20, left[100:120]]
+    want = O.sorted_tuples(O.find_all(O.Text(codes, table), pats, engine=5, k=2, indels=False))
+    with pytest.raises(sat_amd.PmError):
+        _sharded_owned(codes, table, pats, 2, False, 2, guard=64)
+    parts = _sharded_owned(codes, table, pats, 2, False, 2, guard=512)      # wide enough: decided by one shard
+    got = [tuple(int(v) for v in (h["end"], h["pid"], h["k"])) for part in parts for h in part]
+    assert sorted(got) == want
+
+
 def test_cli_lines_via_align_hits():
     """Engine hits + pm_align_hits (the CLI's per-hit re-alignment) reproduce the lines the real
     primer_match prints with -A '%i %r %s %e %S %E %d' (tests/golden cli sections)."""
