@@ -1,0 +1,22 @@
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+__global__ void k(uint32_t *out) {
+  extern __shared__ uint32_t lds[];
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) lds[i] = 0x03020100u + 0x04040404u * i;
+  __syncthreads();
+  const uint32_t base = (uint32_t)(uintptr_t)(lds_u32 *)lds;
+  const uint32_t addr = threadIdx.x;     // byte address, unaligned for most lanes
+  out[threadIdx.x] = *(lds_u32 *)(uintptr_t)addr;
+  if (threadIdx.x == 0) out[256] = base;
+}
+int main() {
+  uint32_t *d; hipMalloc(&d, 4 * 300);
+  hipLaunchKernelGGL(k, dim3(1), dim3(256), 4096, 0, d);
+  uint32_t h[300]; hipMemcpy(h, d, 4 * 300, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int i = 0; i < 256; ++i) { uint32_t want = 0; for (int b = 0; b < 4; ++b) want |= (uint32_t)((i + b) & 0xff) << (8 * b); if (h[i] != want) { if (bad < 5) printf("lane %d got %08x want %08x\n", i, h[i], want); ++bad; } }
+  printf("base=%u bad=%d err=%s\n", h[256], bad, hipGetErrorString(hipGetLastError()));
+  return 0;
+}

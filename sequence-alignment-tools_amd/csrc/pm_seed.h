@@ -13,8 +13,9 @@ constexpr int SEED_THREADS = 1024;                // 16 waves per workgroup, one
 constexpr int SEED_QCAP = 128;                    // first survivor queue (Bloom survivors), entries per wave
 constexpr int SEED_Q2CAP = 112;                   // second queue (second-level bitmap survivors)
 constexpr int SEED_BLOOM_WORDS = 32768;           // 128 KiB blocked Bloom filter per combo
+constexpr int SEED_BLOOM_STRIDE = SEED_BLOOM_WORDS + 4;   // + the bytes a 32-bit block that starts at the last byte reaches (16-byte granule)
 constexpr int SEED_MAX_COMBOS = 16;
-constexpr int SEED_LDS_BYTES = SEED_BLOOM_WORDS * 4 + (SEED_THREADS / 64) * (SEED_QCAP + SEED_Q2CAP) * 8;   // filter + wave queues
+constexpr int SEED_LDS_BYTES = SEED_BLOOM_STRIDE * 4 + (SEED_THREADS / 64) * (SEED_QCAP + SEED_Q2CAP) * 8;   // filter + wave queues
 
 struct SeedTables {
   int k = 0, Lw = 0, pb = 0, r = 0, maxlen = 0, mode = 0;
@@ -23,7 +24,7 @@ struct SeedTables {
   std::vector<uint32_t> perm_sel;         // piece indices of every combo
   size_t nslots = 0;
   int idx_bits = 0, bucket_shift = 0;
-  std::vector<uint32_t> bloom;                    // [combo][SEED_BLOOM_WORDS]
+  std::vector<uint32_t> bloom;                    // [combo][SEED_BLOOM_STRIDE]
   std::vector<uint32_t> slots;                    // [combo][nbuckets][8]
   std::vector<uint32_t> bitmap2;                  // [combo][2^(lb2-5)]
   int lb2 = 0;

@@ -51,7 +51,7 @@ struct SeedArgs {
   uint32_t mask_lo[SEED_MAX_COMBOS];    // window bits (2 per base) that belong to the combo's pieces
   uint32_t mask_hi[SEED_MAX_COMBOS];
   uint32_t perm_sel[SEED_MAX_COMBOS];   // byte-aligned plans (pb == 4): v_perm selector gathering the pieces
-  const uint32_t *bloom;                // [combo][SEED_BLOOM_WORDS]
+  const uint32_t *bloom;                // [combo][SEED_BLOOM_STRIDE]
   const uint4 *buckets;                 // [combo][nbuckets][2]: 8 slots of (fingerprint << idx_bits | pattern index)
   uint32_t bucket_shift, idx_bits;      // bucket = h2 >> bucket_shift; nbuckets = 2^(32-bucket_shift)
   const uint32_t *bitmap2;              // [combo][2^(lb2-5)] second-level one-bit filter (L2 resident)
@@ -159,6 +159,18 @@ __device__ __host__ __forceinline__ uint32_t bloom_selectors(uint32_t selsrc) {
 }
 
 // bit 0 = 1 iff all three selected bits of the Bloom word are set
+// The filter block of a key: the dword at LDS byte address (h >> 15) & ~3 (the 15 best-mixed hash
+// bits).  The address is used as it is -- the filter sits at LDS address 0 (checked at kernel
+// start) -- which saves the add of a block base the compiler cannot fold for dynamic LDS.
+// Byte-granular blocks (no mask) would save one more instruction and gfx950 does serve unaligned
+// ds_read_b32 (scripts/probe/lds_unaligned.hip), but at a price: the scan kernels ran 2x slower.
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+constexpr uint32_t BLOOM_ADDR_MASK = 0x1fffcu;
+__device__ __host__ __forceinline__ uint32_t bloom_addr(uint32_t h) { return (h >> 15) & BLOOM_ADDR_MASK; }
+__device__ __forceinline__ uint32_t bloom_block(uint32_t h) {
+  return *reinterpret_cast<lds_u32 *>((uintptr_t)bloom_addr(h));
+}
+
 __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t hsel) {
   uint32_t a, b, c;
   asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(hsel), "v"(word));
@@ -525,8 +537,9 @@ __device__ __noinline__ void probe_from(const SeedArgs *ap, const uint4 *buckets
 template <int LW, int MODE, bool HALVES, bool EDITS = false>
 __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   extern __shared__ uint32_t lds[];
-  uint32_t *bloom = lds;                                          // SEED_BLOOM_WORDS dwords
-  uint2 *queue_all = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_WORDS);
+  uint32_t *bloom = lds;                                          // SEED_BLOOM_STRIDE dwords, at LDS address 0 (bloom_block)
+  uint2 *queue_all = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_STRIDE);
+  if ((uint32_t)(uintptr_t)(lds_u32 *)lds != 0u) __builtin_trap();   // this kernel has no static LDS: the dynamic block starts at 0
 
   // blockIdx -> (combo, chunk): runs of `group` chunks share a combo, all combos of a superchunk
   // follow each other, so the stream bytes of a superchunk are re-read from MALL and the combo's
@@ -546,9 +559,9 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   if (cj >= a.nchunks || combo >= a.ncombos) return;
 
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.bloom + (size_t)combo * SEED_BLOOM_WORDS);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.bloom + (size_t)combo * SEED_BLOOM_STRIDE);
     u32x4 *dst = reinterpret_cast<u32x4 *>(bloom);
-    for (int i = threadIdx.x; i < SEED_BLOOM_WORDS / 4; i += SEED_THREADS) dst[i] = src[i];
+    for (int i = threadIdx.x; i < SEED_BLOOM_STRIDE / 4; i += SEED_THREADS) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   //   Q2 <- the ~5 % of Q1 that the bitmap lets through.  Only when 64 of them have gathered does
   //   the wave load their buckets and packed patterns (stages 2b/3): one dense pass instead of a
   //   mostly idle one per Q1 batch.
-  uint2 *queue2 = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_WORDS) + WAVES * QCAP + wave * SEED_Q2CAP;
+  uint2 *queue2 = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_STRIDE) + WAVES * QCAP + wave * SEED_Q2CAP;
   int q2n = 0;
   // HALVES: records go to slots reserved SEED_OUT_BLOCK at a time (wave-uniform state)
   unsigned long long ob_next = 0;
@@ -792,23 +805,28 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     // first and second piece; compile-time constants at every call): 16 hashes, 16 LDS reads in
     // flight, three bit tests per window, verdicts funnelled into one register
     auto tests = [&](int sa, int sb) __attribute__((always_inline)) -> uint32_t {
-      uint32_t hs[16], wd[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        uint32_t wlo, whi;
-        window(i, prev2, prev1, cur, wlo, whi);
-        if (EDITS && (sa != 0 || sb != 0)) {
-          const uint32_t wb = sb ? wlo_at(i, sb) : wlo, wa = sa ? wlo_at(i, sa) : wlo;
-          wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
-        }
-        uint32_t ss;
-        const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
-        hs[i] = bloom_selectors(ss);
-        wd[i] = bloom[h >> 17];                                    // word index = the 15 best-mixed bits
-      }
       uint32_t acc = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_alignbit(bloom_test(wd[i], hs[i]), acc, 1);
+      for (int half = 0; half < 2; ++half) {                        // eight reads in flight, then their eight verdicts
+        uint32_t hs[8], wd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = 8 * half + j;
+          uint32_t wlo, whi;
+          window(i, prev2, prev1, cur, wlo, whi);
+          if (EDITS && (sa != 0 || sb != 0)) {
+            const uint32_t wb = sb ? wlo_at(i, sb) : wlo, wa = sa ? wlo_at(i, sa) : wlo;
+            wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
+          }
+          uint32_t ss;
+          const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
+          hs[j] = bloom_selectors(ss);
+          wd[j] = bloom_block(h);
+        }
+        __builtin_amdgcn_sched_barrier(0);                          // without it the scheduler waits for every read by itself
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_alignbit(bloom_test(wd[j], hs[j]), acc, 1);
+      }
       return (acc >> 16) & own;
     };
     // EDITS: the displacement patterns (d1 between third and second piece, d2 between second and
@@ -883,6 +901,12 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
   if (n > v.seed_cap) n = v.seed_cap;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long rounds = (n + stride - 1) / stride;     // same trip count for every lane: ballots below stay whole-wave
+  const int lane = threadIdx.x & 63;
+  // output slots are reserved 64 at a time per wave (one counter serves every wave of the grid and
+  // same-address atomics serialise); what a wave leaves unused is marked PM_SEED_HOLE, which the
+  // dedup that follows drops
+  unsigned long long ob_next = 0;
+  int ob_left = 0;
   for (unsigned long long it = 0; it < rounds; ++it) {
     const unsigned long long i = it * stride + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t res = 0, pid = 0;
@@ -891,6 +915,7 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
       const uint64_t sd = v.seeds[i];
       if (sd != ~0ull) { p = (int64_t)(sd & 0xffffffffffull); res = edits_verify(a, p, (uint32_t)(sd >> 40), &pid); }
     }
+    if (__ballot(res != 0) == 0) continue;
 #pragma unroll 1
     for (int d = 0; d < 5; ++d) {
       const uint32_t lvl1 = (res >> (4 * d)) & 15u;
@@ -898,16 +923,23 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
       const bool pass = lvl1 != 0 && e > a.begin && e <= a.end;
       const unsigned long long bal = __ballot(pass);
       if (bal == 0) continue;
-      const int lane = threadIdx.x & 63;
-      unsigned long long base = 0;
-      if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(a.counter, (unsigned long long)__popcll(bal));
-      base = __shfl(base, __ffsll((long long)bal) - 1);
+      const int c = __popcll(bal);
+      if (c > ob_left) {
+        if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+        ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                  __builtin_amdgcn_readfirstlane((uint32_t)base);
+        ob_left = SEED_OUT_BLOCK;
+      }
       if (pass) {
-        const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
         if (slot < a.cap) a.out[slot] = edit_record(e, pid, lvl1);
       }
+      ob_next += c; ob_left -= c;
     }
   }
+  if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
 }
 
 }  // namespace
@@ -926,7 +958,8 @@ static uint64_t binom(int n, int r) {
 // inserted between two pieces) leaves >= 3 clean pieces, each displaced by the indels to its
 // right.  A placement is found if one of its clean triples is tested under its displacement
 // pattern (d1 = second minus third piece, d2 = first minus second).  Greedy set cover over all
-// placements: 34 pairs for k = 2 (of 85 that can occur, 130 in all), 5 for k = 1.
+// placements: 34 pairs for k = 2 (of 85 that can occur, 130 in all) and 8 for k = 1 -- both equal the
+// optimum of the exact set-cover integer program, so the greedy choice loses nothing here.
 static void edit_cover(int k, int m, const std::vector<std::array<int, 4>> &combos, uint32_t *evar) {
   static const int VD1[13] = {0, 0, 0, 1, -1, 0, 0, 2, -2, 1, 1, -1, -1};
   static const int VD2[13] = {0, 1, -1, 0, 0, 2, -2, 0, 0, 1, -1, 1, -1};
@@ -1073,7 +1106,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.idx_bits = idx_bits; t.bucket_shift = 32 - lb;
   const size_t nslots = nbuckets * 8;
   t.nslots = nslots;
-  t.bloom.assign((size_t)C * SEED_BLOOM_WORDS, 0);
+  t.bloom.assign((size_t)C * SEED_BLOOM_STRIDE, 0);
   int lb2 = 16;
   while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2;
   t.lb2 = lb2;
@@ -1118,9 +1151,13 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
                        : t.mode == 1 ? window_hash<1>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss)
                                      : window_hash<2>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss);
       const uint32_t hsel = bloom_selectors(ss);
-      static_assert(SEED_BLOOM_WORDS == 1 << 15, "word index = h >> 17");
-      t.bloom[(size_t)ci * SEED_BLOOM_WORDS + (h >> 17)] |=
-          (1u << ((hsel >> 8) & 31)) | (1u << ((hsel >> 16) & 31)) | (1u << ((hsel >> 24) & 31));
+      static_assert(SEED_BLOOM_WORDS == 1 << 15, "block address = h >> 15");
+      {
+        // the key's block: the dword at byte bloom_addr(h) (bloom_block on the device)
+        const uint32_t bits = (1u << ((hsel >> 8) & 31)) | (1u << ((hsel >> 16) & 31)) | (1u << ((hsel >> 24) & 31));
+        uint8_t *blk = reinterpret_cast<uint8_t *>(&t.bloom[(size_t)ci * SEED_BLOOM_STRIDE]) + bloom_addr(h);
+        for (int q = 0; q < 4; ++q) blk[q] |= (uint8_t)(bits >> (8 * q));
+      }
       const uint32_t h2 = h * HASH_SLOT;
       t.bitmap2[((size_t)ci << (lb2 - 5)) + (h2 >> (37 - lb2))] |= 1u << ((h2 >> (32 - lb2)) & 31);
       const uint32_t imask = (1u << idx_bits) - 1u;
