@@ -139,9 +139,13 @@ int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t scanned_to,
 
 /* Device form of pm_finalize: the records are in HBM (d_cands, or NULL = those of the last
  * pm_scan_candidates), the sort + clustering runs on the GPU and only final hits cross PCIe into
- * `out`.  Available where the host stage needs neither stream text nor sequential state: exact
- * engines, bare shift_and_inexact, and filter_bitvec with -K and no exact-base constraints
- * (PM_E_UNSUPPORTED otherwise: use pm_finalize). */
+ * `out`.  Available for: exact engines and bare shift_and_inexact (pass-through); filter_bitvec
+ * with -K and no exact-base constraints (sort + segmented pass), and with -k on the seed family
+ * (A,C,G,T patterns of 20..32 characters, k <= 2: clusters and their DPs on the GPU against the
+ * text in HBM); exact_halves on the seed family (exact_halves.cc:142,163,178: its per-pattern
+ * "end beyond the last kept end" rule as a sort + one walk per pattern -- stateless, so only with
+ * PM_FINALIZE_LAST on an engine state that is fresh since pm_init / pm_reset).
+ * PM_E_UNSUPPORTED otherwise: use pm_finalize. */
 int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                        pm_hit *out, size_t cap, size_t *n_out);
 

@@ -106,6 +106,11 @@ struct pm_handle {
   unsigned long long *d_fcounts = nullptr, *h_fcounts = nullptr;
   uint8_t *d_fpat_len = nullptr;
   uint32_t *d_fpat_id = nullptr;
+  // exact_halves rule on the device: payload arrays and the pair sort's workspace
+  uint32_t *d_vals = nullptr, *d_vals_alt = nullptr;
+  void *d_htemp = nullptr;
+  size_t vals_cap = 0, htemp_bytes = 0;
+  bool halves_fresh = true;           // no host-side exact_halves state (lasthit, carried seeds) since init / pm_reset
 
   std::string err;
 };
@@ -188,7 +193,8 @@ static void free_device(pm_handle *h) {
   if (h->d_wlen) (void)hipFree(h->d_wlen);
   if (h->d_woff) (void)hipFree(h->d_woff);
   if (h->d_wout) (void)hipFree(h->d_wout);
-  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id};
+  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id, h->d_vals, h->d_vals_alt, h->d_htemp};
+  h->d_vals = h->d_vals_alt = nullptr; h->d_htemp = nullptr; h->vals_cap = 0; h->htemp_bytes = 0;
   for (void *q : fw) if (q) (void)hipFree(q);
   if (h->h_fcounts) (void)hipHostFree(h->h_fcounts);
   h->d_keys = h->d_keys_alt = nullptr; h->d_ctemp = nullptr; h->d_fout = h->d_fleft = nullptr; h->d_fcounts = nullptr;
@@ -254,6 +260,7 @@ static int resolve(pm_handle *h) {
         h->inner.push_back(Pattern{s.substr(l1), 0, 0, 0});    h->inner_ids.push_back((uint32_t)(2 * i + 2));
       }
       h->lasthit.assign(np + 1, 0);
+      h->halves_fresh = true;
       break;
     case PM_SEM_EXACT_BASES:                                        // exact_bases.cc:131-160
       for (int i = 0; i < np; ++i) {
@@ -454,6 +461,7 @@ extern "C" int pm_reset(pm_handle *h) {
   if (!h) return PM_E_INVALID;
   h->carry.clear(); h->ready.clear(); h->ready_pos = 0; h->next_begin = 0;
   std::fill(h->lasthit.begin(), h->lasthit.end(), 0);
+  h->halves_fresh = true;
   h->last_count = 0; h->scan_pending = false;
   return PM_OK;
 }
@@ -1054,6 +1062,7 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
       break;
     case PM_SEM_FILTER_BITVEC: rc = finalize_filter_bitvec(h, cands, n, scanned_to, last, outv); break;
     case PM_SEM_EXACT_HALVES:
+      h->halves_fresh = false;
       rc = h->seed_flags ? finalize_halves_flags(h, cands, n, scanned_to, last, outv)
          : h->halves_dev ? finalize_extended(h, cands, n, outv) : finalize_seeds(h, cands, n, true, outv);
       break;
@@ -1121,6 +1130,45 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   // edits on the seed family (A,C,G,T patterns of <= 32 characters): clusters and their DPs on the device
   const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && h->pats.size() < ((size_t)1 << 22);
   if (cluster_dp) cluster = true;
+  // exact_halves on the seed family: its per-pattern sequential rule as a sort + one walk per pattern
+  // (pm_halves_rule).  Stateless, so only for a complete range on a fresh engine state.
+  const bool halves = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && h->pats.size() < ((size_t)1 << 22) - 1;
+  if (halves) {
+    if (!last || own.on || !h->halves_fresh || !h->carry.empty())
+      return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: exact_halves on the device needs the whole range in one call after pm_reset (use pm_finalize)");
+    const size_t m = h->seed_flags ? 2 * n : n;
+    { int rcw = ensure_sort_workspace(h, m, true); if (rcw) return rcw; }
+    if (h->vals_cap < h->ckeys_cap) {
+      void *old[] = {h->d_vals, h->d_vals_alt, h->d_htemp};
+      for (void *q : old) if (q) (void)hipFree(q);
+      h->d_vals = h->d_vals_alt = nullptr; h->d_htemp = nullptr;
+      h->vals_cap = h->ckeys_cap;
+      HIP_TRY(h, hipMalloc((void **)&h->d_vals, h->vals_cap * 4));
+      HIP_TRY(h, hipMalloc((void **)&h->d_vals_alt, h->vals_cap * 4));
+      h->htemp_bytes = halves_temp_bytes(h->vals_cap);
+      HIP_TRY(h, hipMalloc(&h->d_htemp, h->htemp_bytes ? h->htemp_bytes : 16));
+    }
+    if (!h->d_fpat_len) {
+      std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
+      for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
+      HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));
+      HIP_TRY(h, hipMalloc((void **)&h->d_fpat_id, pi.size() ? pi.size() * 4 : 4));
+      if (!pl.empty()) {
+        HIP_TRY(h, hipMemcpy(h->d_fpat_len, pl.data(), pl.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
+      }
+    }
+    HIP_TRY(h, halves_rule_device(src, n, h->seed_flags, h->cfg.indels ? 2 * h->cfg.k : 0, h->d_fpat_len, h->d_fpat_id, h->d_keys, h->d_keys_alt,
+                                  h->d_vals, h->d_vals_alt, h->d_htemp, h->htemp_bytes, h->d_fout, h->d_fcounts, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t nfin = (size_t)h->h_fcounts[0];
+    if (nfin > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
+    if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));
+    if (flags & PM_FINALIZE_SORTED) std::sort(out, out + nfin, by_end_pid);
+    if (n_out) *n_out = nfin;
+    return PM_OK;
+  }
   if (!passthrough && !cluster) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this option set needs the host stage (pm_finalize)");
   if (passthrough) {
     if (n > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
@@ -1315,9 +1363,11 @@ extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, si
     }
     if (rc) return rc;
     std::vector<pm_hit> outv;
-    if (h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && h->pats.size() < ((size_t)1 << 22)) {
+    const bool halves_whole = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && begin == 0 && end >= h->n &&
+                              h->halves_fresh && h->carry.empty() && h->pats.size() < ((size_t)1 << 22) - 1;
+    if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && h->pats.size() < ((size_t)1 << 22)) || halves_whole) {
       // clusters and their DPs on the device (pm_cluster_dp); only what it hands back goes through the host stage
-      outv.resize(cnt + h->carry.size() + 16);
+      outv.resize((h->seed_flags ? 2 * cnt : cnt) + h->carry.size() + 16);
       size_t nout = 0;
       rc = pm_finalize_device(h, nullptr, 0, end, end >= h->n ? PM_FINALIZE_LAST : 0, outv.data(), outv.size(), &nout);
       if (rc) return rc;

@@ -306,6 +306,94 @@ hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t
   return hipGetLastError();
 }
 
+// ---- exact_halves: the per-pattern "end beyond the last kept end" rule on the device -------------
+// exact_halves.cc:114-118,142,163,178: seed hits are visited in (position asc, inner id desc) order
+// and a hit is kept when its end exceeds the pattern's last kept end (by more than 2k with edits).
+// The rule only couples hits of one pattern, so: one sort key per seed
+//   pattern(22) | seed position(40) | left half(1)     (right half = larger inner id = first)
+// with (end - seed position, value) as the payload, a radix sort, and one thread per pattern
+// walking its run.  Stateless: the caller guarantees a fresh engine state and a complete range.
+namespace {
+
+constexpr uint64_t HALVES_HOLE = ~0ull;
+
+__device__ __forceinline__ uint64_t halves_key(uint32_t j, int64_t seedpos, bool left) {
+  return ((uint64_t)j << 41) | (((uint64_t)seedpos & 0xffffffffffull) << 1) | (left ? 1u : 0u);
+}
+
+// whole-pattern Hamming candidates with clean-half flags (finalize_halves_flags): two seeds per record
+__global__ void pm_halves_pack_flags(const pm_hit *in, size_t n, const uint8_t *pat_len, uint64_t *keys, uint32_t *vals) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pm_hit h = in[i];
+  const int L = pat_len[h.pid - 1], len2 = L - L / 2;
+  keys[2 * i] = (h.aux[0] & 1) ? halves_key(h.pid, h.end - len2, true) : HALVES_HOLE;
+  vals[2 * i] = ((uint32_t)len2 << 8) | h.k;
+  keys[2 * i + 1] = (h.aux[0] & 2) ? halves_key(h.pid, h.end, false) : HALVES_HOLE;
+  vals[2 * i + 1] = h.k;
+}
+
+// extended half seeds (pm_extend.hip): {end = seed position, pid = inner id, k, aux[0] = end - position}
+__global__ void pm_halves_pack_seeds(const pm_hit *in, size_t n, uint64_t *keys, uint32_t *vals) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pm_hit h = in[i];
+  if (h.pid == PM_SEED_HOLE) { keys[i] = HALVES_HOLE; vals[i] = 0; return; }
+  keys[i] = halves_key((h.pid + 1) / 2, h.end, (h.pid & 1u) != 0);
+  vals[i] = ((uint32_t)h.aux[0] << 8) | h.k;
+}
+
+__global__ void pm_halves_rule(const uint64_t *keys, const uint32_t *vals, size_t n, int slack, const uint32_t *pat_id,
+                               pm_hit *out, unsigned long long *out_count) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == HALVES_HOLE) return;
+  const uint32_t j = (uint32_t)(key >> 41);
+  if (i > 0 && (uint32_t)(keys[i - 1] >> 41) == j) return;         // not the first seed of its pattern
+  int64_t lasthit = 0;                                             // fresh engine state (pm_api.cpp lasthit)
+  for (size_t t = i; t < n; ++t) {
+    const uint64_t kt = keys[t];
+    if (kt == HALVES_HOLE || (uint32_t)(kt >> 41) != j) break;
+    const uint32_t v = vals[t];
+    const int64_t end = (int64_t)((kt >> 1) & 0xffffffffffull) + (int64_t)(v >> 8);
+    if (end > lasthit + slack) {
+      lasthit = end;
+      const unsigned long long o = atomicAdd(out_count, 1ull);     // runs are short and heads are sparse: no aggregation to gain
+      pm_hit h;
+      h.pid = pat_id[j - 1]; h.end = end; h.k = (uint8_t)(v & 0xffu); h.aux[0] = h.aux[1] = h.aux[2] = 0;
+      out[o] = h;
+    }
+  }
+}
+
+}  // namespace
+
+size_t halves_temp_bytes(size_t n) {
+  size_t bytes = 0;
+  uint64_t *k = nullptr; uint32_t *v = nullptr;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, v, v, (int)n);
+  return bytes;
+}
+
+// flags != 0: records are whole-pattern candidates with clean-half flags (two seeds each, d_keys /
+// d_vals need 2n slots); otherwise extended half seeds.  Finals to d_out, their number to d_counts[0].
+hipError_t halves_rule_device(const pm_hit *d_in, size_t n, bool flags, int slack, const uint8_t *d_pat_len, const uint32_t *d_pat_id,
+                              uint64_t *d_keys, uint64_t *d_keys_alt, uint32_t *d_vals, uint32_t *d_vals_alt, void *d_temp, size_t temp_bytes,
+                              pm_hit *d_out, unsigned long long *d_counts, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), st);
+  if (e != hipSuccess || n == 0) return e;
+  const int threads = 256;
+  const size_t m = flags ? 2 * n : n;
+  const unsigned blocks = (unsigned)((n + threads - 1) / threads), mblocks = (unsigned)((m + threads - 1) / threads);
+  if (flags) hipLaunchKernelGGL(pm_halves_pack_flags, dim3(blocks), dim3(threads), 0, st, d_in, n, d_pat_len, d_keys, d_vals);
+  else hipLaunchKernelGGL(pm_halves_pack_seeds, dim3(blocks), dim3(threads), 0, st, d_in, n, d_keys, d_vals);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_keys_alt, d_vals, d_vals_alt, (int)m, 0, 64, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(pm_halves_rule, dim3(mblocks), dim3(threads), 0, st, d_keys_alt, d_vals_alt, m, slack, d_pat_id, d_out, d_counts);
+  return hipGetLastError();
+}
+
 size_t cluster_temp_bytes(size_t n) {
   size_t bytes = 0;
   uint64_t *p = nullptr;

@@ -104,6 +104,12 @@ hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, i
                              const uint32_t *d_pat_id, const OwnedRange &own, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                              pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
 
+// exact_halves' sequential per-pattern rule on the device (pm_cluster.hip)
+size_t halves_temp_bytes(size_t n);
+hipError_t halves_rule_device(const pm_hit *d_in, size_t n, bool flags, int slack, const uint8_t *d_pat_len, const uint32_t *d_pat_id,
+                              uint64_t *d_keys, uint64_t *d_keys_alt, uint32_t *d_vals, uint32_t *d_vals_alt, void *d_temp, size_t temp_bytes,
+                              pm_hit *d_out, unsigned long long *d_counts, hipStream_t st);
+
 // ---- seed extension DP on the GPU (pm_extend.hip) ---------------------------------------------
 hipError_t extend_seeds(const uint8_t *d_text, int64_t n, const pm_hit *d_seeds, size_t nseeds,
                         const uint8_t *d_half_codes, const uint8_t *d_half_len, const int32_t *d_esb, const int32_t *d_eeb,

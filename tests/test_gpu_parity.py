@@ -205,13 +205,48 @@ def test_device_finalize_equals_host_finalize():
         b = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
         assert sorted(a + b) == host, (k, "split")
         pm.close()
-    pm = sat_amd.PatternMatch(k=1, indels=True)         # exact_halves: its sequential rule stays on the host
-    pm.add_pattern("ACGTACGTACGTACGTACGT", 1)
-    pm.init(codes, table)
-    pm.scan_candidates(0, n, to_host=False)
-    with pytest.raises(sat_amd.PmError):
-        pm.finalize_device(n)
-    pm.close()
+
+
+@pytest.mark.parametrize("case", ["varlen_repeats", "dense_indels", "small_mixed"])
+def test_device_halves_rule_equals_host_stage(case):
+    """exact_halves (-K 1 on whole-pattern candidates with clean-half flags, -k 1 on extended half
+    seeds): the per-pattern "end beyond the last kept end" rule as a device sort + walk
+    (pm_halves_rule) == the host stage == the oracle, incl. tandem repeats where the rule bites.
+    It is stateless: a partial range, or host-side state, sends the caller to pm_finalize."""
+    c, codes, table, allp = load([p for p in CASES if case in p][0])
+    n = codes.size
+    for indels in (False, True):
+        pats = [p for p in allp if 16 <= len(p) <= 32] if indels else allp
+        if len(pats) < 4:
+            continue
+        pm = sat_amd.PatternMatch(k=1, indels=indels, semantics=sat_amd.SEM_EXACT_HALVES)
+        for i, p in enumerate(pats):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        want = O.sorted_tuples(O.find_all(O.Text(codes, table), pats, engine=sat_amd.SEM_EXACT_HALVES, k=1, indels=indels))
+        pm.scan_candidates(0, n, to_host=False)
+        try:
+            dev = sat_amd.sorted_tuples(pm.finalize_device(n, last=True))
+        except sat_amd.PmError as e:
+            assert e.code == -2 and pm.selected()[1] != sat_amd.KERNEL_SEED      # bit-parallel family: host stage only
+            pm.close()
+            continue
+        assert dev == want and len(want) > 0, (case, indels, len(dev), len(want))
+        cands = pm.scan_candidates(0, n)
+        host = sat_amd.sorted_tuples(pm.finalize(cands, n, last=True))
+        assert host == want
+        pm.scan_candidates(0, n, to_host=False)
+        with pytest.raises(sat_amd.PmError):             # host-side state now exists: not fresh
+            pm.finalize_device(n, last=True)
+        pm.reset()
+        pm.scan_candidates(0, n // 2, to_host=False)
+        with pytest.raises(sat_amd.PmError):             # partial range
+            pm.finalize_device(n // 2, last=False)
+        pm.reset()
+        hits = []
+        pm.find_patterns(hits, chunk=n + 1)              # pm_scan over the whole stream takes the device path
+        assert sorted((h[0], h[1], h[2]) for h in hits) == want
+        pm.close()
 
 
 @pytest.mark.parametrize("case", ["varlen_repeats", "dense_indels", "small_mixed"])
