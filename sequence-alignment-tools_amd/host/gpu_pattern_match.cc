@@ -8,6 +8,17 @@ namespace pmgpu {
 
 BufferChars::BufferChars(std::vector<unsigned char> bytes, std::string table)
     : bytes_(std::move(bytes)), table_(std::move(table)) {
+  data_ = bytes_.data();
+  n_ = (int64_t)bytes_.size();
+  build_inverse();
+}
+
+BufferChars::BufferChars(const unsigned char *data, size_t n, std::string table)
+    : data_(data), n_((int64_t)n), table_(std::move(table)) {
+  build_inverse();
+}
+
+void BufferChars::build_inverse() {
   for (int i = 0; i < 256; ++i) inv_[i] = table_.empty() ? i : -1;
   for (size_t i = 0; i < table_.size(); ++i) inv_[(unsigned char)table_[i]] = (int)i;
 }

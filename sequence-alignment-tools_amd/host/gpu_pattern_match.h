@@ -35,18 +35,23 @@ class CharacterProducer {                       // reference char_io.h:18-71 (su
 class BufferChars : public CharacterProducer {
  public:
   BufferChars(std::vector<unsigned char> bytes, std::string table);   // table empty = raw stream
-  unsigned char getnch() override { return bytes_[pos_++]; }
+  // bytes owned by someone else (a file mapping, seq_io.h) who outlives this object
+  BufferChars(const unsigned char *data, size_t n, std::string table);
+  unsigned char getnch() override { return data_[pos_++]; }
   char ch(unsigned char c) override { return table_.empty() ? (char)c : table_[c]; }
   int nch(char c) override { return inv_[(unsigned char)c]; }
   unsigned int size() const override { return table_.empty() ? 256u : (unsigned)table_.size(); }
-  int64_t length() const override { return (int64_t)bytes_.size(); }
-  bool eof() const override { return pos_ >= (int64_t)bytes_.size(); }
+  int64_t length() const override { return n_; }
+  bool eof() const override { return pos_ >= n_; }
   int64_t pos() const override { return pos_; }
   void pos(int64_t p) override { pos_ = p; }
   bool has_filename() const override { return true; }
-  const char *c_str() const override { return reinterpret_cast<const char *>(bytes_.data()); }
+  const char *c_str() const override { return reinterpret_cast<const char *>(data_); }
  private:
+  void build_inverse();
   std::vector<unsigned char> bytes_;
+  const unsigned char *data_ = nullptr;
+  int64_t n_ = 0;
   std::string table_;
   int inv_[256];
   int64_t pos_ = 0;

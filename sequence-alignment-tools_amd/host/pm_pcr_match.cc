@@ -318,7 +318,7 @@ int main(int argc, char **argv) {
 
   // ---- database and engine (pcr_match.cc:911-931) -------------------------------------------
   ph.mark("Read primer pairs");
-  SeqDb db(opt.database, opt.dbind, /*load_headers=*/true, /*check=*/true, /*upper_case=*/false, opt.eos_char);
+  SeqDb db(opt.database, opt.dbind, /*load_headers=*/true, /*check=*/true, /*upper_case=*/false, opt.eos_char, opt.memmap);
   ph.mark("Loaded sequence database");
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
   if (opt.node == 16) kernel = PM_KERNEL_BITPAR;

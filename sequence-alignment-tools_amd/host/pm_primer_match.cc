@@ -354,7 +354,7 @@ int main(int argc, char **argv) {
   }
 
   // ---- database and engine (primer_match.cc:1086-1112) --------------------------------------
-  SeqDb db(opt.database, opt.dbind, opt.alignments && opt.dbindex, opt.dbindex, opt.ucdict, opt.eos_char);
+  SeqDb db(opt.database, opt.dbind, opt.alignments && opt.dbindex, opt.dbindex, opt.ucdict, opt.eos_char, opt.memmap);
   ph.mark("Loaded sequence database");
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
   if (opt.node == 16) kernel = PM_KERNEL_BITPAR;

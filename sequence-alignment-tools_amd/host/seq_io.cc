@@ -1,7 +1,10 @@
 // seq_io.cc -- see seq_io.h.
 #include "seq_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -65,22 +68,50 @@ bool read_file(const std::string &path, std::vector<unsigned char> *out) {
   return got == out->size();
 }
 
-SeqDb::SeqDb(const std::string &database, int format, bool load_headers, bool check, bool upper_case, char eos_char) {
+MappedFile::~MappedFile() {
+  if (data_) munmap(const_cast<unsigned char *>(data_), size_);
+}
+
+bool MappedFile::open(const std::string &path) {
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return false; }
+  size_ = (size_t)st.st_size;
+  if (size_ == 0) { close(fd); data_ = nullptr; return true; }
+  void *p = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { size_ = 0; return false; }
+  data_ = static_cast<const unsigned char *>(p);
+  return true;
+}
+
+SeqDb::SeqDb(const std::string &database, int format, bool load_headers, bool check, bool upper_case, char eos_char, bool memmap) {
   std::vector<unsigned char> bytes;
+  bool mapped = false;
+  auto load = [&](const std::string &path) -> bool {
+    if (memmap && map_.open(path)) { mapped = true; return true; }
+    return read_file(path, &bytes);
+  };
   if ((format == 0 && file_exists(database + ".sqn")) || format == 3) {          // select.t:30
     normalized_ = true;
     std::vector<unsigned char> tb;
-    if (!read_file(database + ".sqn", &bytes) || !read_file(database + ".tbl", &tb))
+    if (!load(database + ".sqn") || !read_file(database + ".tbl", &tb))
       die(("Can't open normalized sequence database " + database + ".sqn/.tbl").c_str());
     table_.assign(tb.begin(), tb.end());
   } else if ((format == 0 && file_exists(database + ".seq")) || format == 2) {   // select.t:118
-    if (!read_file(database + ".seq", &bytes)) die(("Can't open indexed sequence database " + database + ".seq").c_str());
+    if (!load(database + ".seq")) die(("Can't open indexed sequence database " + database + ".seq").c_str());
   } else {
     die("This build reads databases prepared by compress_seq (<db>.seq or <db>.sqn + <db>.tbl, <db>.idb, <db>.hdr);",
         "run pm_compress_seq -i <fasta> [-n true] first.");
   }
-  length_ = (int64_t)bytes.size();
-  chars_ = new BufferChars(std::move(bytes), table_);
+  if (mapped) {
+    length_ = (int64_t)map_.size();
+    chars_ = new BufferChars(map_.data(), map_.size(), table_);
+  } else {
+    length_ = (int64_t)bytes.size();
+    chars_ = new BufferChars(std::move(bytes), table_);
+  }
 
   std::vector<int64_t> ikeys, ivals;
   const bool need_index = check || load_headers;

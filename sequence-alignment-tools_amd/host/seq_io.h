@@ -26,6 +26,22 @@ void uppercase(std::string &s);
 bool file_exists(const std::string &path);
 bool read_file(const std::string &path, std::vector<unsigned char> *out);
 
+// Read-only mapping of a whole file (what MapFileChars is to the reference, char_io.h:122-175);
+// the pages come straight from the page cache, nothing is copied.
+class MappedFile {
+ public:
+  MappedFile() {}
+  ~MappedFile();
+  MappedFile(const MappedFile &) = delete;
+  MappedFile &operator=(const MappedFile &) = delete;
+  bool open(const std::string &path);
+  const unsigned char *data() const { return data_; }
+  size_t size() const { return size_; }
+ private:
+  const unsigned char *data_ = nullptr;
+  size_t size_ = 0;
+};
+
 struct HeaderData {                                   // Lazy_Header_SI (fasta_io.t:93-140)
   unsigned long index = 0;
   std::string header, short_header;
@@ -37,7 +53,8 @@ class SeqDb {
   // load_headers = the `alignments && dbindex` argument of pick_fasta_file (primer_match.cc:1093).
   // check = ffp.check_params; upper_case / eos_char: ffp fields (fasta_io.t:18-30).
   // Errors follow the reference: message on stderr, exit(1).
-  SeqDb(const std::string &database, int format, bool load_headers, bool check, bool upper_case, char eos_char);
+  // memmap: map the sequence file (the reference's default) instead of reading it (-B, BufferedFileChars).
+  SeqDb(const std::string &database, int format, bool load_headers, bool check, bool upper_case, char eos_char, bool memmap = true);
   BufferChars &chars() { return *chars_; }
   bool normalized() const { return normalized_; }
   const std::string &table() const { return table_; }
@@ -49,6 +66,7 @@ class SeqDb {
  private:
   bool locate(int64_t pos, size_t *idx) const;       // last entry with key <= pos-1
   BufferChars *chars_ = nullptr;
+  MappedFile map_;
   bool normalized_ = false;
   std::string table_;
   int64_t length_ = 0;
