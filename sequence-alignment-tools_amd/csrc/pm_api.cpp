@@ -429,15 +429,80 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   return pm_reset(h);
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Host stream -> HBM.  A single hipMemcpy from pageable memory runs at the speed of one core's copy
+// into the runtime's staging buffer (≈11 GB/s here); several threads, each staging its slice
+// through two pinned buffers of its own on its own HIP stream, fill the PCIe link instead.
+static hipError_t upload_stream(int device, void *d, const uint8_t *text, size_t n) {
+  constexpr size_t CH = (size_t)8 << 20;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int T = (int)std::min<size_t>(std::min<unsigned>(6u, hw), (n + 4 * CH - 1) / (4 * CH));
+  if (T <= 1) return hipMemcpy(d, text, n, hipMemcpyHostToDevice);
+  std::vector<hipError_t> errs((size_t)T, hipSuccess);
+  std::vector<std::thread> th;
+  const size_t per = ((n + (size_t)T - 1) / (size_t)T + CH - 1) / CH * CH;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+    hipError_t e = hipSetDevice(device);
+    const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+    hipStream_t st = nullptr;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+      e = hipHostMalloc(&pin[b], CH, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+    }
+    int b = 0;
+    for (size_t off = lo; off < hi && e == hipSuccess; off += CH, b ^= 1) {
+      const size_t len = std::min(CH, hi - off);
+      e = hipEventSynchronize(ev[b]);                               // the copy that last used this buffer is done
+      if (e != hipSuccess) break;
+      memcpy(pin[b], text + off, len);
+      e = hipMemcpyAsync((char *)d + off, pin[b], len, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipEventRecord(ev[b], st);
+    }
+    if (st) { const hipError_t e2 = hipStreamSynchronize(st); if (e == hipSuccess) e = e2; }
+    for (int q = 0; q < 2; ++q) { if (ev[q]) (void)hipEventDestroy(ev[q]); if (pin[q]) (void)hipHostFree(pin[q]); }
+    if (st) (void)hipStreamDestroy(st);
+    errs[(size_t)t] = e;
+  });
+  for (std::thread &x : th) x.join();
+  for (hipError_t e : errs) if (e != hipSuccess) return e;
+  return hipSuccess;
+}
+
 extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8_t *table, int32_t table_len) {
   if (!h || (!text && n > 0) || n < 0) return fail(h, PM_E_INVALID, "pm_init: bad arguments");
+  const double ti0 = now_ms();
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   if (h->own_d_text && h->d_text) { (void)hipFree((void *)h->d_text); h->d_text = nullptr; }
   void *d = nullptr;
   HIP_TRY(h, hipMalloc(&d, (size_t)(n > 0 ? n : 1) + 16));
-  if (n > 0) HIP_TRY(h, hipMemcpy(d, text, (size_t)n, hipMemcpyHostToDevice));
+  const double ti1 = now_ms();
   h->d_text = (const uint8_t *)d; h->own_d_text = true; h->h_text = text; h->n = n; h->stream = nullptr;
-  return init_common(h, table, table_len);
+  // the stream crosses PCIe (≈0.3 s for 3 GB of pageable memory) while this thread builds the
+  // pattern tables; raw streams with wildcards look at the stream on the device first, so they wait
+  const bool overlap = n > ((int64_t)1 << 24) && !(!table && h->cfg.wildcards);
+  hipError_t copy_err = hipSuccess;
+  std::thread copier;
+  if (n > 0) {
+    if (overlap) {
+      const int dev = h->cfg.device;
+      copier = std::thread([=, &copy_err]() {
+        copy_err = hipSetDevice(dev);
+        if (copy_err == hipSuccess) copy_err = upload_stream(dev, d, text, (size_t)n);
+      });
+    } else {
+      HIP_TRY(h, hipMemcpy(d, text, (size_t)n, hipMemcpyHostToDevice));
+    }
+  }
+  const int rc = init_common(h, table, table_len);
+  const double ti2 = now_ms();
+  if (copier.joinable()) copier.join();
+  if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] init: runtime + stream buffer %.0f ms, tables %.0f ms, then %.0f ms more for the stream upload\n", ti1 - ti0, ti2 - ti1, now_ms() - ti2);
+  if (copy_err != hipSuccess) return fail(h, PM_E_HIP, std::string("pm_init: stream upload: ") + hipGetErrorString(copy_err));
+  return rc;
 }
 
 extern "C" int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *table, int32_t table_len,
@@ -538,7 +603,6 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   return PM_OK;
 }
 
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // sort workspace shared by pm_finalize_device (clustering) and the edit-distance dedup
 static int ensure_sort_workspace(pm_handle *h, size_t n, bool with_out) {

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace pm {
 
@@ -1142,10 +1143,15 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       rec[20] = (uint8_t)L; rec[21] = t.part_len[j]; rec[22] = t.part_side[j]; rec[23] = 0;
       memcpy(rec + 24, &idv, 4);
     }
-    for (int ci = 0; ci < C; ++ci) {
-      uint64_t cm = 0;
-      for (int q = 0; q < t.r; ++q) cm |= pmask << (2 * t.pb * t.combos[ci][q]);
-      const uint32_t wlo = (uint32_t)w, whi = (uint32_t)(w >> 32), mlo = (uint32_t)cm, mhi = (uint32_t)(cm >> 32);
+  }
+  // filter, second-level bitmap and bucket table per combo: the combos' tables are disjoint, and
+  // the inserts are cache misses into megabytes of table, so one thread per combo
+  auto build_combo = [&](int ci) {
+    uint64_t cm = 0;
+    for (int q = 0; q < t.r; ++q) cm |= pmask << (2 * t.pb * t.combos[ci][q]);
+    const uint32_t mlo = (uint32_t)cm, mhi = (uint32_t)(cm >> 32);
+    for (size_t j = 0; j < np; ++j) {
+      const uint32_t wlo = t.pat40[j].lo, whi = t.pat40[j].hi;
       uint32_t ss = 0;
       const uint32_t h = t.mode == 0 ? window_hash<0>(wlo, whi, mlo, mhi, 0, &ss)
                        : t.mode == 1 ? window_hash<1>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss)
@@ -1170,6 +1176,14 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
         b = (b + 1) & (uint32_t)(nbuckets - 1);
       }
     }
+  };
+  if (np * (size_t)C < 20000) {
+    for (int ci = 0; ci < C; ++ci) build_combo(ci);
+  } else {
+    const int T = (int)std::min<unsigned>((unsigned)C, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (int w = 0; w < T; ++w) th.emplace_back([&, w]() { for (int ci = w; ci < C; ci += T) build_combo(ci); });
+    for (std::thread &x : th) x.join();
   }
   return "";
 }
