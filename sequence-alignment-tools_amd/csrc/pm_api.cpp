@@ -107,6 +107,8 @@ struct pm_handle {
   uint8_t *d_fpat_len = nullptr;
   uint32_t *d_fpat_id = nullptr;
   // exact_halves rule on the device: payload arrays and the pair sort's workspace
+  pm_hit *d_carry = nullptr;          // carried candidates of an earlier range, uploaded for the device clustering
+  size_t d_carry_cap = 0;
   uint32_t *d_vals = nullptr, *d_vals_alt = nullptr;
   void *d_htemp = nullptr;
   size_t vals_cap = 0, htemp_bytes = 0;
@@ -193,8 +195,8 @@ static void free_device(pm_handle *h) {
   if (h->d_wlen) (void)hipFree(h->d_wlen);
   if (h->d_woff) (void)hipFree(h->d_woff);
   if (h->d_wout) (void)hipFree(h->d_wout);
-  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id, h->d_vals, h->d_vals_alt, h->d_htemp};
-  h->d_vals = h->d_vals_alt = nullptr; h->d_htemp = nullptr; h->vals_cap = 0; h->htemp_bytes = 0;
+  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id, h->d_vals, h->d_vals_alt, h->d_htemp, h->d_carry};
+  h->d_vals = h->d_vals_alt = nullptr; h->d_htemp = nullptr; h->vals_cap = 0; h->htemp_bytes = 0; h->d_carry = nullptr; h->d_carry_cap = 0;
   for (void *q : fw) if (q) (void)hipFree(q);
   if (h->h_fcounts) (void)hipHostFree(h->h_fcounts);
   h->d_keys = h->d_keys_alt = nullptr; h->d_ctemp = nullptr; h->d_fout = h->d_fleft = nullptr; h->d_fcounts = nullptr;
@@ -1160,6 +1162,14 @@ extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
 static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                                 const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out);
 
+// filter_bitvec with -K and no exact-base constraints: its verify is "smallest level, left-most end"
+// (pm_cluster.hip), no stream text needed
+static bool device_cluster_plain(const pm_handle *h) {
+  if (!(h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.indels && h->cfg.k <= 3 && h->pats.size() < ((size_t)1 << 22))) return false;
+  for (const Pattern &p : h->pats) if (p.esb || p.eeb) return false;
+  return true;
+}
+
 extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                                   pm_hit *out, size_t cap, size_t *n_out) {
   const OwnedRange all = {0, 0, 0, 0, 0};
@@ -1189,11 +1199,9 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   const bool last = flags & PM_FINALIZE_LAST;
   if (n_out) *n_out = 0;
   const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT;
-  bool cluster = h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.indels && h->cfg.k <= 3 && h->pats.size() < ((size_t)1 << 22);
-  if (cluster) for (const Pattern &p : h->pats) if (p.esb || p.eeb) { cluster = false; break; }
   // edits on the seed family (A,C,G,T patterns of <= 32 characters): clusters and their DPs on the device
   const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && h->pats.size() < ((size_t)1 << 22);
-  if (cluster_dp) cluster = true;
+  const bool cluster = cluster_dp || device_cluster_plain(h);
   // exact_halves on the seed family: its per-pattern sequential rule as a sort + one walk per pattern
   // (pm_halves_rule).  Stateless, so only for a complete range on a fresh engine state.
   const bool halves = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && h->pats.size() < ((size_t)1 << 22) - 1;
@@ -1243,7 +1251,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     if (n_out) *n_out = n;
     return PM_OK;
   }
-  { int rcw = ensure_sort_workspace(h, n, true); if (rcw) return rcw; }
+  { int rcw = ensure_sort_workspace(h, n + h->carry.size(), true); if (rcw) return rcw; }
   if (!h->d_fpat_len) {
     std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
     for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
@@ -1271,16 +1279,28 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
       HIP_TRY(h, hipMemcpy(h->d_dp_eeb, ee.data(), np * 4, hipMemcpyHostToDevice));
     }
   }
-  // carried candidates from an earlier call join the batch on the host side (they are few)
+  // candidates an earlier range left undecided (clusters that could still grow) join this batch on
+  // the device: their chains continue here
   std::vector<pm_hit> hostpart;
-  hostpart.swap(h->carry);
+  const size_t ncarry = h->carry.size();
+  if (ncarry) {
+    if (h->d_carry_cap < ncarry) {
+      if (h->d_carry) (void)hipFree(h->d_carry);
+      h->d_carry = nullptr;
+      h->d_carry_cap = ncarry + ncarry / 2 + 1024;
+      HIP_TRY(h, hipMalloc((void **)&h->d_carry, h->d_carry_cap * sizeof(pm_hit)));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_carry, h->carry.data(), ncarry * sizeof(pm_hit), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->carry.clear();
+  }
   const double tfd0 = now_ms();
   if (cluster_dp)
-    HIP_TRY(h, cluster_dp_device(src, n, h->cfg.k, true, scanned_to, last, h->d_text, h->n, h->eos_code, h->d_dp_codes, h->d_fpat_len,
+    HIP_TRY(h, cluster_dp_device(src, n, h->d_carry, ncarry, h->cfg.k, true, scanned_to, last, h->d_text, h->n, h->eos_code, h->d_dp_codes, h->d_fpat_len,
                                  h->d_dp_esb, h->d_dp_eeb, h->d_fpat_id, own, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes,
                                  h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
   else
-  HIP_TRY(h, cluster_device(src, n, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, own, h->d_keys, h->d_keys_alt,
+  HIP_TRY(h, cluster_device(src, n, h->d_carry, ncarry, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, own, h->d_keys, h->d_keys_alt,
                             h->d_ctemp, h->ctemp_bytes, h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
   h->h_fcounts[2] = 0;
   HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, (n ? 3 : 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -1429,7 +1449,8 @@ extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, si
     std::vector<pm_hit> outv;
     const bool halves_whole = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && begin == 0 && end >= h->n &&
                               h->halves_fresh && h->carry.empty() && h->pats.size() < ((size_t)1 << 22) - 1;
-    if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && h->pats.size() < ((size_t)1 << 22)) || halves_whole) {
+    if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && h->pats.size() < ((size_t)1 << 22)) || halves_whole ||
+        (device_cluster_plain(h) && h->kern == PM_KERNEL_SEED)) {
       // clusters and their DPs on the device (pm_cluster_dp); only what it hands back goes through the host stage
       outv.resize((h->seed_flags ? 2 * cnt : cnt) + h->carry.size() + 16);
       size_t nout = 0;

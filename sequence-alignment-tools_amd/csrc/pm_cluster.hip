@@ -272,19 +272,22 @@ __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels,
 
 }  // namespace
 
-// Clustering + one DP per cluster for filter_bitvec with edits.  Records in any order (duplicates and
+// Clustering + one DP per cluster for filter_bitvec with edits.  Records (two arrays: this range's and
+// the ones an earlier range left undecided) in any order (duplicates and
 // holes allowed); finals to d_out / d_counts[0], records the host stage must look at to d_left / d_counts[1],
 // chains cut by the guard edge of an owned range counted in d_counts[2].
-hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, int64_t scanned_to, bool last,
+hipError_t cluster_dp_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, bool indels, int64_t scanned_to, bool last,
                              const uint8_t *d_text, int64_t ntext, int eos_code,
                              const uint8_t *d_pat_codes, const uint8_t *d_pat_len, const int32_t *d_esb, const int32_t *d_eeb,
                              const uint32_t *d_pat_id, const OwnedRange &own, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                              pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st) {
   hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), st);
+  const size_t n = n1 + n2;
   if (e != hipSuccess || n == 0) return e;
   const int threads = 256;
   const unsigned blocks = (unsigned)((n + threads - 1) / threads);
-  hipLaunchKernelGGL(pm_dedup_pack, dim3(blocks), dim3(threads), 0, st, d_in, n, d_keys);
+  if (n1) hipLaunchKernelGGL(pm_dedup_pack, dim3((unsigned)((n1 + threads - 1) / threads)), dim3(threads), 0, st, d_in, n1, d_keys);
+  if (n2) hipLaunchKernelGGL(pm_dedup_pack, dim3((unsigned)((n2 + threads - 1) / threads)), dim3(threads), 0, st, d_in2, n2, d_keys + n1);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(pm_cluster_dp, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, k, indels ? 1 : 0, scanned_to, last ? 1 : 0,
@@ -401,15 +404,17 @@ size_t cluster_temp_bytes(size_t n) {
   return bytes;
 }
 
-hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_to, bool last,
+hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, int64_t scanned_to, bool last,
                           const uint8_t *d_pat_len, const uint32_t *d_pat_id, const OwnedRange &own,
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st) {
   hipError_t e = hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), st);
+  const size_t n = n1 + n2;
   if (e != hipSuccess || n == 0) return e;
   const int threads = 256;
   const unsigned blocks = (unsigned)((n + threads - 1) / threads);
-  hipLaunchKernelGGL(pm_cluster_pack, dim3(blocks), dim3(threads), 0, st, d_in, n, d_keys);
+  if (n1) hipLaunchKernelGGL(pm_cluster_pack, dim3((unsigned)((n1 + threads - 1) / threads)), dim3(threads), 0, st, d_in, n1, d_keys);
+  if (n2) hipLaunchKernelGGL(pm_cluster_pack, dim3((unsigned)((n2 + threads - 1) / threads)), dim3(threads), 0, st, d_in2, n2, d_keys + n1);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(pm_cluster_reduce, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, 2 * k + 1, scanned_to, last ? 1 : 0,

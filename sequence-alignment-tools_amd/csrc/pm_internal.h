@@ -85,7 +85,7 @@ hipError_t gather_windows(const uint8_t *d_text, int64_t n, const int64_t *d_sta
 struct OwnedRange { int64_t own_lo, own_hi, guard_lo, guard_hi; int on; };
 
 size_t cluster_temp_bytes(size_t n);
-hipError_t cluster_device(const pm_hit *d_in, size_t n, int k, int64_t scanned_to, bool last,
+hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, int64_t scanned_to, bool last,
                           const uint8_t *d_pat_len, const uint32_t *d_pat_id, const OwnedRange &own,
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
@@ -98,7 +98,7 @@ constexpr int SEED_OUT_BLOCK = 64;               // slots a wave reserves per at
 hipError_t dedup_device(const pm_hit *d_in, size_t n, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                         pm_hit *d_out, unsigned long long *d_count, hipStream_t st);
 
-hipError_t cluster_dp_device(const pm_hit *d_in, size_t n, int k, bool indels, int64_t scanned_to, bool last,
+hipError_t cluster_dp_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, bool indels, int64_t scanned_to, bool last,
                              const uint8_t *d_text, int64_t ntext, int eos_code,
                              const uint8_t *d_pat_codes, const uint8_t *d_pat_len, const int32_t *d_esb, const int32_t *d_eeb,
                              const uint32_t *d_pat_id, const OwnedRange &own, uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
