@@ -14,5 +14,5 @@ with open("/dev/shm/pmprimers.txt", "wb") as f:
     for i in range(100000):
         f.write(lut[rng.integers(0, 4, size=20)].tobytes() + b"\n")
 PY
-for i in 1 2; do PM_DEBUG=1 sequence-alignment-tools_amd/host/pm_primer_match -i /dev/shm/pmdb -P /dev/shm/pmprimers.txt -K 2 -r -c -v 2>&1 >/dev/null | grep "^\[pm\]\|^\[ \|scan (find" ; done
+for i in 1; do PM_DEBUG=1 sequence-alignment-tools_amd/host/pm_primer_match -i /dev/shm/pmdb -P /dev/shm/pmprimers.txt -K 2 -r -c -v 2>&1 >/dev/null | grep -v "^$" ; done
 rm -f /dev/shm/pmdb.* /dev/shm/pmprimers.txt
