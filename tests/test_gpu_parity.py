@@ -542,3 +542,47 @@ def test_edit_distance_device_text_with_repeat_clusters():
         got = sat_amd.sorted_tuples(pm.find_all(chunk=chunk))
         pm.close()
         assert got == want and len(want) > 0, (chunk, len(got), len(want))
+
+
+def test_large_host_stream_upload_equals_device_stream():
+    """pm_init with a host stream large enough for the threaded, pinned-staged upload that runs
+    beside the table build (pm_api.cpp upload_stream): same hits as the same bytes handed over
+    already resident (pm_init_device), and the planted sites are all there."""
+    import torch
+    rng = np.random.default_rng(2026)
+    n = 100_000_000 + 12345                                  # not a multiple of the staging chunk
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    codes[0] = 4
+    codes[-1] = 4
+    codes[rng.integers(1, n - 1, size=40)] = 4               # entry separators
+    table = b"ACGT\n"
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pats, sites = [], []
+    for t in range(200):
+        a = int(rng.integers(1, n - 40))
+        w = codes[a:a + 20]
+        if (w > 3).any():
+            continue
+        pats.append(lut[w].tobytes().decode())
+        sites.append(a + 20)
+    # sites near the slice edges of the upload threads (6 slices, 8 MiB chunks)
+    for a in (n // 6 - 10, 2 * (n // 6) + 3, (8 << 20) - 7, n - 30):
+        w = codes[a:a + 20]
+        if (w <= 3).all():
+            pats.append(lut[w].tobytes().decode())
+            sites.append(a + 20)
+    res = []
+    for mode in ("host", "device"):
+        pm = sat_amd.PatternMatch(k=1, indels=False)
+        for i, p in enumerate(pats):
+            pm.add_pattern(p, i + 1)
+        if mode == "host":
+            pm.init(codes, table)
+        else:
+            dev = torch.from_numpy(codes).to("cuda:0")
+            pm.init_device(dev.data_ptr(), dev.numel(), table, keepalive=dev)
+        res.append(sat_amd.sorted_tuples(pm.find_all()))
+        pm.close()
+    assert res[0] == res[1] and len(res[0]) >= len(pats)
+    found = {(e, p) for e, p, k in res[0] if k == 0}
+    assert all((sites[i], i + 1) in found for i in range(len(pats)))
