@@ -346,14 +346,17 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     // One LDS Bloom filter (1 Mbit) stays selective up to ~256k keys: larger pattern sets are cut
     // into tiles with their own tables; the scan launches once per tile into the same record buffer.
     size_t tile_keys = 262144;
-    if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
-    const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
-    size_t per = (sp.size() + ntile - 1) / ntile;
-    if (halves_mode) per += per & 1;                // keep (left, right) half pairs together: side = index parity
     // the plan (window, pieces) must be the same for every tile: it depends on the shortest pattern
     // of the whole set, so every tile is built with that window forced
     int force_lw = 0;
     for (const Pattern &p : sp) force_lw = force_lw == 0 ? (int)p.s.size() : std::min(force_lw, (int)p.s.size());
+    // halves of <= 10 bases: the filter is the exact bitmap of their keys (SeedArgs::exact_filter) and
+    // has no capacity to exceed -- one pass over the stream for all of them
+    if (halves_mode && force_lw > 0 && force_lw <= 10) tile_keys = (size_t)1 << 21;
+    if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
+    const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
+    size_t per = (sp.size() + ntile - 1) / ntile;
+    if (halves_mode) per += per & 1;                // keep (left, right) half pairs together: side = index parity
     for (size_t ti = 0; ti < ntile && why.empty(); ++ti) {
       const size_t lo = ti * per, hi = std::min(sp.size(), lo + per);
       std::vector<Pattern> tp(sp.begin() + lo, sp.begin() + hi);

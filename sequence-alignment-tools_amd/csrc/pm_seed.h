@@ -35,6 +35,7 @@ struct SeedTables {
   std::vector<uint8_t> pat_codes;                 // 32 bytes per pattern
   bool halves = false; int hk = 0;                // exact_halves -k mode: partner half per pattern
   int hfast = 0;                                  // see SeedArgs::hfast
+  bool exact_filter = false;                      // see SeedArgs::exact_filter
   int edits = 0;                                  // > 0: edit-distance seed plan for this k (records in pat_codes)
   int eos_code = -1;
   std::vector<uint32_t> part32;
@@ -49,6 +50,7 @@ struct SeedDevice {
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr;
   uint32_t *part32 = nullptr;
   bool halves = false; int hk = 0, hfast = 0, eos_code = -1, edits = 0;
+  bool exact_filter = false;
   uint32_t emask_a[SEED_MAX_COMBOS] = {}, emask_b[SEED_MAX_COMBOS] = {}, evar[SEED_MAX_COMBOS] = {};
   uint32_t mask_lo[SEED_MAX_COMBOS] = {}, mask_hi[SEED_MAX_COMBOS] = {}, perm_sel[SEED_MAX_COMBOS] = {};
   int mode = 0;

@@ -71,6 +71,8 @@ struct SeedArgs {
   uint64_t *seed_out;                   // EDITS scan: 8-byte seed records (pattern index << 40 | position), ~0 = unused slot
   uint32_t emask_a[SEED_MAX_COMBOS], emask_b[SEED_MAX_COMBOS];   // byte masks (low window word) of the combo's first and second piece
   uint32_t evar[SEED_MAX_COMBOS];       // bit v: displacement pattern v is tested for this combo (edit_cover on the host)
+  int exact_filter;                     // halves with keys of <= 20 bits (one piece of <= 10 bases): the LDS filter is the exact
+                                        // key bitmap (bit = key), no false positives, and the second-level bitmap is skipped
   int hfast;                            // > 0: every pattern has this length and half j lies on side j & 1, so the
                                         // partner's stream window is known before the half's record is read
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
@@ -757,9 +759,13 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     if (q < qn) {
       const uint2 e = queue[q];
       pw = e.x; px = e.y;
-      const uint32_t h2 = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
-      pt = h2 >> (32 - a.lb2);                                     // bit index inside the bitmap
-      pb = bitmap2[h2 >> (37 - a.lb2)];
+      if (HALVES && a.exact_filter) {                              // nothing false came through the key bitmap
+        pt = 0; pb = 1u;
+      } else {
+        const uint32_t h2 = window_hash<MODE>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
+        pt = h2 >> (32 - a.lb2);                                     // bit index inside the bitmap
+        pb = bitmap2[h2 >> (37 - a.lb2)];
+      }
     }
   };
   auto drain = [&]() __attribute__((always_inline)) {             // qn <= QCAP = 128 = 2 per lane
@@ -801,6 +807,7 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
       const int s = 2 * (i - Lw + 33) + 2 * d;                     // 22 .. 60
       return s < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, s) : __builtin_amdgcn_alignbit(cur, prev1, s - 32);
     };
+    const bool exact = HALVES && a.exact_filter != 0;
     const uint32_t ema = EDITS ? a.emask_a[combo] : 0u, emb = EDITS ? a.emask_b[combo] : 0u, evar = EDITS ? a.evar[combo] : 0u;
     // first stage, parts 1 and 2 for one displacement pattern (sa, sb = displacement of the combo's
     // first and second piece; compile-time constants at every call): 16 hashes, 16 LDS reads in
@@ -819,14 +826,25 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
             const uint32_t wb = sb ? wlo_at(i, sb) : wlo, wa = sa ? wlo_at(i, sa) : wlo;
             wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
           }
-          uint32_t ss;
-          const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
-          hs[j] = bloom_selectors(ss);
-          wd[j] = bloom_block(h);
+          if (HALVES && MODE == 0 && exact) {                       // wave-uniform: bit `key` of the key bitmap
+            const uint32_t key = wlo & mlo;
+            hs[j] = key;
+            wd[j] = *reinterpret_cast<lds_u32 *>((uintptr_t)((key >> 3) & ~3u));
+          } else {
+            uint32_t ss;
+            const uint32_t h = window_hash<MODE>(wlo, whi, mlo, mhi, sel, &ss);
+            hs[j] = bloom_selectors(ss);
+            wd[j] = bloom_block(h);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);                          // without it the scheduler waits for every read by itself
+        if (HALVES && MODE == 0 && exact) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_alignbit(bloom_test(wd[j], hs[j]), acc, 1);
+          for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_alignbit(wd[j] >> (hs[j] & 31u), acc, 1);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_alignbit(bloom_test(wd[j], hs[j]), acc, 1);
+        }
       }
       return (acc >> 16) & own;
     };
@@ -1090,6 +1108,8 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       for (size_t i = 0; i < ps.size(); ++i) { const int b2 = base2((unsigned char)ps[i]); if (b2 < 0) return "pattern with characters other than A,C,G,T"; w2 |= (uint32_t)b2 << (2 * i); }
       t.part32[j] = w2; t.part_len[j] = (uint8_t)ps.size(); t.part_side[j] = (*sides)[j];
     }
+  // halves whose key is one piece of <= 10 bases at the low end of the window: 4^10 keys = the bits of the LDS filter
+  t.exact_filter = partners != nullptr && t.mode == 0 && C == 1 && t.r == 1 && t.combos[0][0] == 0 && 2 * t.pb <= 20;
   t.hfast = 0;
   if (partners && np > 0) {                        // same total length everywhere and side = parity of the index?
     const int tot = (int)pats[0].s.size() + t.part_len[0];
@@ -1158,7 +1178,10 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
                                      : window_hash<2>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss);
       const uint32_t hsel = bloom_selectors(ss);
       static_assert(SEED_BLOOM_WORDS == 1 << 15, "block address = h >> 15");
-      {
+      if (t.exact_filter) {
+        const uint32_t key = wlo & mlo;                           // < 2^20 = the filter's bit count
+        t.bloom[(size_t)ci * SEED_BLOOM_STRIDE + (key >> 5)] |= 1u << (key & 31u);
+      } else {
         // the key's block: the dword at byte bloom_addr(h) (bloom_block on the device)
         const uint32_t bits = (1u << ((hsel >> 8) & 31)) | (1u << ((hsel >> 16) & 31)) | (1u << ((hsel >> 24) & 31));
         uint8_t *blk = reinterpret_cast<uint8_t *>(&t.bloom[(size_t)ci * SEED_BLOOM_STRIDE]) + bloom_addr(h);
@@ -1217,7 +1240,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part32.data(), t.part32.size() * 4, (void **)&d->part32)) != hipSuccess) return e;
   if ((e = up(t.part_len.data(), t.part_len.size(), (void **)&d->part_len)) != hipSuccess) return e;
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
-  d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code;
+  d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code; d->exact_filter = t.exact_filter;
   d->edits = t.edits;
   for (int c = 0; c < d->ncombos; ++c) {              // byte masks of the combo's first and second piece (edits: displaced pieces)
     d->emask_a[c] = t.r >= 3 && t.combos[c][0] < 4 ? 0xffu << (8 * t.combos[c][0]) : 0u;
@@ -1277,7 +1300,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, in
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));
   a.bloom = d.bloom; a.buckets = reinterpret_cast<const uint4 *>(d.slots); a.bucket_shift = (uint32_t)d.bucket_shift; a.idx_bits = (uint32_t)d.idx_bits;
   a.bitmap2 = d.bitmap2; a.lb2 = (uint32_t)d.lb2;
-  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code;
+  a.halves = d.halves ? 1 : 0; a.hk = d.hk; a.hfast = d.hfast; a.eos_code = d.eos_code; a.exact_filter = d.exact_filter ? 1 : 0;
   a.edits = d.edits; a.maxlen = d.maxlen;
   memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); memcpy(a.evar, d.evar, sizeof(a.evar)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
