@@ -265,6 +265,7 @@ def main():
     own_path = world > 1 and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC
     g_lo = 0 if glo == 0 else begin - GUARD
     g_hi = stream.numel() if ghi == total else end + GUARD
+    land_stream = torch.cuda.Stream(device=dev) if rank == 0 and own_path else None
     all_pin = torch.empty((1 << 24) * 2 * (world if own_path else 1), dtype=torch.int64, pin_memory=True) if rank == 0 and own_path else None
     dev_final = [True]                                              # GPU clustering available for this option set?
 
@@ -296,7 +297,7 @@ def main():
         mine = torch.tensor([cnt], dtype=torch.int64, device=cdev)
         clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
         dist.all_gather(clist, mine)
-        cl = [int(x.item()) for x in clist]
+        cl = torch.cat(clist).tolist()                                  # one host sync for all counts
         mx = max(max(cl), 1)
         pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)
         if cnt:
@@ -304,13 +305,22 @@ def main():
         gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, gathered, dst=0)
         if rank == 0:
-            at = 0
-            for r in range(world):
-                a = gathered[r][:cl[r] * 2].view(-1, 2)
-                a[:, 0] += max(0, r * shard - GUARD - HALO)            # local -> global stream index
-                all_pin[at:at + cl[r] * 2].copy_(a.reshape(-1), non_blocking=True)   # shards are in stream order
-                at += cl[r] * 2
-            torch.cuda.synchronize()
+            # landing on the host: index fix-up and copy into pinned memory on a side stream, so that it
+            # overlaps the next step's scan (the timed region ends with a device-wide synchronize)
+            cur = torch.cuda.current_stream()
+            land = land_stream if cdev.type == "cuda" else cur
+            land.wait_stream(cur)
+            with torch.cuda.stream(land):
+                at = 0
+                for r in range(world):
+                    a = gathered[r][:cl[r] * 2].view(-1, 2)
+                    a[:, 0] += max(0, r * shard - GUARD - HALO)        # local -> global stream index
+                    all_pin[at:at + cl[r] * 2].copy_(a.reshape(-1), non_blocking=True)   # shards are in stream order
+                    if gathered[r].is_cuda:
+                        gathered[r].record_stream(land)
+                    at += cl[r] * 2
+            if cdev.type != "cuda":
+                torch.cuda.synchronize()
             cand_count[0] = at // 2
             final_hits[0] = at // 2
         return ncand
