@@ -1,3 +1,8 @@
+// Hardware probe (not product code): does gfx950 serve ds_read_b32 at byte addresses that are not
+// multiples of four, and where does a kernel's dynamic LDS block start?  Build and run on the GPU box:
+//   hipcc -O3 --offload-arch=gfx950 scripts/probe/lds_unaligned.hip -o scripts/probe/lds_unaligned && scripts/probe/lds_unaligned
+// Result on MI355X: every lane reads the four bytes at its byte address (base=0); the scan kernels
+// nevertheless ran 2x slower with byte-granular filter blocks, so pm_seed.hip keeps dword blocks.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
