@@ -9,7 +9,8 @@
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 __global__ void k(uint32_t *out) {
   extern __shared__ uint32_t lds[];
-  for (int i = threadIdx.x; i < 1024; i += blockDim.x) lds[i] = 0x03020100u + 0x04040404u * i;
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x)          // byte b of the block holds b & 255
+    lds[i] = ((4u * i) & 255u) | (((4u * i + 1u) & 255u) << 8) | (((4u * i + 2u) & 255u) << 16) | (((4u * i + 3u) & 255u) << 24);
   __syncthreads();
   const uint32_t base = (uint32_t)(uintptr_t)(lds_u32 *)lds;
   const uint32_t addr = threadIdx.x;     // byte address, unaligned for most lanes
