@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--indels", type=int, default=0, help="0: -K (mismatches), 1: -k (edits)")
     ap.add_argument("--kernel", choices=["auto", "bitpar", "seed"], default="auto")
+    ap.add_argument("--odd", type=int, default=0, help="replace this many primers by ones with an N in the middle (they go to the bit-parallel residue engine)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-sample", type=int, default=0, help="bases for the CPU baseline (0 = auto, -1 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -237,6 +238,8 @@ def main():
         box = [primers]
         dist.broadcast_object_list(box, src=0, device=cdev)
         primers = box[0]
+    if args.odd:
+        primers = [p[:len(p) // 2] + "N" + p[len(p) // 2 + 1:] if i < args.odd else p for i, p in enumerate(primers)]
     allp = primers + [sat_amd.reverse_comp(p) for p in primers]
     kern = {"auto": sat_amd.KERNEL_AUTO, "bitpar": sat_amd.KERNEL_BITPAR, "seed": sat_amd.KERNEL_SEED}[args.kernel]
     pm = sat_amd.PatternMatch(k=args.k, indels=bool(args.indels), kernel=kern, device=local)

@@ -112,6 +112,8 @@ struct pm_handle {
   uint32_t *d_vals = nullptr, *d_vals_alt = nullptr;
   void *d_htemp = nullptr;
   size_t vals_cap = 0, htemp_bytes = 0;
+  std::vector<uint8_t> in_rest;       // per inner pattern: 1 = scanned by the bit-parallel residue engine beside the seed family
+  size_t nrest = 0;
   bool halves_fresh = true;           // no host-side exact_halves state (lasthit, carried seeds) since init / pm_reset
 
   std::string err;
@@ -293,7 +295,11 @@ static bool seed_eligible(pm_handle *h, std::string *why) {
   if (h->cfg.k > 0 && h->cfg.indels && (sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_SHIFT_AND_INEXACT)) {
     // the automaton's candidates from displaced-piece seeds + a per-seed automaton run (pm_seed.hip, EDITS)
     if (h->cfg.k > 2) { *why = "edit distance > 2 runs on the bit-parallel family"; return false; }
-    for (const Pattern &p : h->pats) if (p.s.size() > 32 || p.s.size() < 20) { *why = "the edit-distance seed plan needs 20..32 character patterns"; return false; }
+    for (size_t i = 0; i < h->pats.size(); ++i) {
+      if (i < h->in_rest.size() && h->in_rest[i]) continue;         // goes to the bit-parallel residue
+      const Pattern &p = h->pats[i];
+      if (p.s.size() > 32 || p.s.size() < 20) { *why = "the edit-distance seed plan needs 20..32 character patterns"; return false; }
+    }
     for (uint32_t id : h->inner_ids) if (id >= (1u << 22)) { *why = "the edit-distance seed plan packs pattern ids into 22 bits"; return false; }
     return true;
   }
@@ -322,6 +328,23 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->start_cached = false; h->start_cache.clear();
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
+  // A pattern set is rarely uniform: a few primers with an ambiguity letter, one that is too short
+  // or too long for the seed plan.  Where the engines' records mean the same (one inner pattern per
+  // pattern: keyword_tree, shift_and, shift_and_inexact, filter_bitvec) those few are scanned by
+  // the bit-parallel kernels into the same record buffer and the rest stays on the seed family.
+  h->in_rest.assign(h->inner.size(), 0);
+  h->nrest = 0;
+  const bool edits_plan = h->cfg.indels && h->cfg.k > 0 && (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT);
+  if (want_seed && !h->cfg.wildcards && h->kern == PM_KERNEL_AUTO &&
+      (h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT || h->sem == PM_SEM_FILTER_BITVEC)) {
+    for (size_t i = 0; i < h->inner.size(); ++i) {
+      const std::string &ps = h->inner[i].s;
+      bool ok = ps.size() <= 32 && ps.size() >= (edits_plan ? 20u : 10u);
+      for (unsigned char ch : ps) ok = ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+      if (!ok) { h->in_rest[i] = 1; ++h->nrest; }
+    }
+    if (h->nrest == h->inner.size()) { std::fill(h->in_rest.begin(), h->in_rest.end(), 0); h->nrest = 0; }   // nothing for the seed family: one engine
+  }
   if (want_seed && !seed_eligible(h, &why)) {
     if (h->kern == PM_KERNEL_SEED) return fail(h, PM_E_UNSUPPORTED, "seed engine: " + why);
     want_seed = false;
@@ -342,6 +365,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     } else if (h->sem == PM_SEM_EXACT_HALVES) {   // -K: whole patterns, distance <= k, halves decided by flags
       for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back((uint32_t)(i + 1)); }
       sk = h->cfg.k;
+    } else if (h->nrest) {
+      for (size_t i = 0; i < h->inner.size(); ++i) if (!h->in_rest[i]) { sp.push_back(h->inner[i]); sid.push_back(h->inner_ids[i]); }
     } else { sp = h->inner; sid = h->inner_ids; }
     // One LDS Bloom filter (1 Mbit) stays selective up to ~256k keys: larger pattern sets are cut
     // into tiles with their own tables; the scan launches once per tile into the same record buffer.
@@ -381,6 +406,14 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       if (h->kern == PM_KERNEL_SEED) return fail(h, PM_E_UNSUPPORTED, "seed engine: " + why);
       want_seed = false;
     } else {
+      if (h->nrest) {
+        std::vector<Pattern> rp; std::vector<uint32_t> rid;
+        for (size_t i = 0; i < h->inner.size(); ++i) if (h->in_rest[i]) { rp.push_back(h->inner[i]); rid.push_back(h->inner_ids[i]); }
+        BitparTables tabs;
+        std::string msg = bitpar_build(rp, rid, h->alpha, h->scan_k, h->eos_code, &tabs, false, false);
+        if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine (residue): " + msg);
+        HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
+      }
       int mx = h->sd.maxlen;
       for (SeedDevice &d : h->sd_more) mx = std::max(mx, d.maxlen);
       h->sd.maxlen = mx;
@@ -414,6 +447,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   }
   if (!want_seed) {
     h->halves_dev = false; h->edits_dev = false;
+    std::fill(h->in_rest.begin(), h->in_rest.end(), 0); h->nrest = 0;
     h->kern = PM_KERNEL_BITPAR;
     BitparTables tabs;
     std::string msg = bitpar_build(h->inner, h->inner_ids, h->alpha, h->scan_k, h->eos_code, &tabs,
@@ -549,10 +583,15 @@ extern "C" int pm_selected_kernel(const pm_handle *h) { return h && h->inited ? 
 
 extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   if (!h || !buf || !h->inited) return PM_E_INVALID;
-  if (h->kern == PM_KERNEL_SEED)
+  if (h->kern == PM_KERNEL_SEED) {
     snprintf(buf, buflen, "kernel=pm_seed_scan tiles=%d combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
              1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
              h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
+    if (h->nrest) {
+      const size_t at = strlen(buf);
+      if (at < buflen) snprintf(buf + at, buflen - at, " + %s for %zu patterns the seed plan does not take", bitpar_kernel_name(h->scan_k, h->scan_indels), h->nrest);
+    }
+  }
   else
     snprintf(buf, buflen, "kernel=%s tiles=%d lanes_per_tile=64 words_per_lane=%d seg_len=%lld nseg=%d grid=%d block=%d",
              bitpar_kernel_name(h->scan_k, h->scan_indels), h->bp.ntiles, BP_WPL, (long long)h->geo.seg_len, h->geo.nseg,
@@ -590,6 +629,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->last_launches = 2 * ntiles;
+    if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }
   else if (h->kern == PM_KERNEL_SEED)
   {
@@ -597,6 +637,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     for (SeedDevice &d : h->sd_more)
       HIP_TRY(h, seed_launch(d, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr));
     h->last_launches = 1 + (int)h->sd_more.size();
+    if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }
   else
     HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
@@ -647,6 +688,7 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
   if (h->h_text) memcpy(head, h->h_text, (size_t)T);
   else HIP_TRY(h, hipMemcpy(head, h->d_text, (size_t)T, hipMemcpyDeviceToHost));
   for (size_t j = 0; j < h->inner.size(); ++j) {
+    if (j < h->in_rest.size() && h->in_rest[j]) continue;           // the residue engine reports its own
     const std::string &s = h->inner[j].s;
     const int L = (int)s.size();
     uint64_t R[3] = {0, 1, 3};
@@ -688,6 +730,7 @@ static int stream_start_candidates(pm_handle *h) {
   }
   std::vector<pm_hit> extra;
   for (size_t j = 0; j < h->inner.size(); ++j) {
+    if (j < h->in_rest.size() && h->in_rest[j]) continue;           // the residue engine reports its own
     const std::string &s = h->inner[j].s;
     const int L = (int)s.size();
     for (int d = 1; d <= k && d < L; ++d) {

@@ -586,3 +586,54 @@ def test_large_host_stream_upload_equals_device_stream():
     assert res[0] == res[1] and len(res[0]) >= len(pats)
     found = {(e, p) for e, p, k in res[0] if k == 0}
     assert all((sites[i], i + 1) in found for i in range(len(pats)))
+
+
+def test_mixed_pattern_set_splits_between_engines():
+    """A primer list is rarely uniform.  A few patterns the seed plan does not take (an ambiguity
+    letter, 17 or 40 characters) are scanned by the bit-parallel kernels into the same record
+    buffer; everything else stays on the seed family.  Same hits as the oracle's engine for every
+    option set whose engines report one inner pattern per pattern."""
+    rng = np.random.default_rng(99)
+    ents = synth.make_entries(rng, 4, 6000, n_runs=2, repeats=True, short=True)
+    base = [p for p in synth.make_patterns(rng, ents, 120, length=22, planted=0.8) if set(p) <= set("ACGT") and len(p) >= 20]
+    odd = []
+    e0 = ents[0]
+    for a in (100, 900, 1700):
+        w = e0[a:a + 21]
+        if set(w) <= set("ACGT"):
+            odd.append(w[:9] + "N" + w[10:])                       # an N in the pattern: a mismatch everywhere (no -w)
+            odd.append(w[:17])                                     # too short for the edit-distance plan
+    w = ents[1][300:340]
+    if set(w) <= set("ACGT"):
+        odd.append(w)                                              # too long for every seed plan
+        odd.append(synth.mutate(rng, w, nsub=1))
+    assert len(odd) >= 4
+    pats = base[:40] + odd + base[40:]
+    allp = pats + [synth.revcomp(p) if set(p) <= set("ACGT") else p for p in pats]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    for k, indels, sem in ((0, False, sat_amd.SEM_AUTO), (2, False, sat_amd.SEM_AUTO), (2, True, sat_amd.SEM_AUTO), (1, True, sat_amd.SEM_FILTER_BITVEC),
+                           (2, True, sat_amd.SEM_SHIFT_AND_INEXACT), (1, False, sat_amd.SEM_SHIFT_AND_INEXACT)):
+        pm = sat_amd.PatternMatch(k=k, indels=indels, semantics=sem)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        s, kern = pm.selected()
+        assert kern == sat_amd.KERNEL_SEED and "patterns the seed plan does not take" in pm.describe(), (k, indels, pm.describe())
+        want = O.sorted_tuples(O.find_all(text, allp, engine=s, k=k, indels=indels))
+        for chunk in (1 << 26, 5000):
+            got = sat_amd.sorted_tuples(pm.find_all(chunk=chunk))
+            assert got == want and len(want) > 0, (k, indels, sem, chunk, len(got), len(want))
+        if s == sat_amd.SEM_FILTER_BITVEC:                         # device clustering sees both engines' records
+            pm.reset()
+            pm.scan_candidates(0, codes.size, to_host=False)
+            assert sat_amd.sorted_tuples(pm.finalize_device(codes.size, last=True)) == want
+        pm.close()
+    # every pattern outside the seed plan: one engine, as before
+    pm = sat_amd.PatternMatch(k=2, indels=True)
+    for i, p in enumerate(odd):
+        pm.add_pattern(p, i + 1)
+    pm.init(codes, table)
+    assert pm.selected()[1] == sat_amd.KERNEL_BITPAR
+    pm.close()
