@@ -38,6 +38,8 @@ struct BitparArgs {
   int64_t n, begin, end;        // owned hit ends: begin < end_pos <= end
   int64_t seg_len, seg0;
   int nseg, ntiles, halo;
+  int nstr;                     // text-parallel form: pattern strings (lanes of the tables) in use
+  int64_t sub_len;              // text-parallel form: stream characters per lane (seg_len = 64 * sub_len)
   const uint32_t *U, *S, *LAST, *INIT, *lane_first, *pid_of;
   const uint8_t *cmap;
   pm_hit *out;
@@ -194,6 +196,117 @@ __global__ __launch_bounds__(256) void pm_bitpar_scan(BitparArgs a) {
   }
 }
 
+// Text-parallel form for small pattern sets.  pm_bitpar_scan gives every lane of a wave its own
+// 256-bit string of patterns and all 64 the same stream character; a dozen patterns then keep one
+// lane of 64 busy and a pass over the stream has a floor of ~150 ms per Gbp.  Here the roles are
+// swapped: every lane of a wave runs the SAME pattern string (masks loaded as broadcasts) over its
+// OWN run of sub_len stream characters (+ halo in front to warm the state up), the character
+// class picks the mask row per lane (select chain instead of a scalar branch).  One wave per
+// (64 runs, pattern string); used while the set has few strings (bitpar_launch).
+template <int K, bool INDELS>
+__global__ __launch_bounds__(256) void pm_bitpar_scan_tp(BitparArgs a) {
+  __shared__ uint8_t s_cmap[256];
+  s_cmap[threadIdx.x] = a.cmap[threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const long wv = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= (long)a.nseg * a.nstr) return;            // wave-uniform
+  const int str = (int)(wv % a.nstr);
+  const int tile = str >> 6, sl = str & 63;
+  const int64_t seg = a.seg0 + wv / a.nstr;
+
+  const int64_t pos0 = seg * a.seg_len + (int64_t)lane * a.sub_len;     // multiple of 16
+  const int64_t own_lo = pos0 > a.begin ? pos0 : a.begin;
+  int64_t own_hi = pos0 + a.sub_len;
+  if (own_hi > a.end) own_hi = a.end;
+  if (own_hi > a.n) own_hi = a.n;
+  int64_t start = pos0 - a.halo;
+  const bool at0 = start <= 0;                         // this lane's run begins at the true start of the stream
+  if (at0) start = 0;
+  const int64_t nchar = own_lo < own_hi ? own_hi - start : 0;
+
+  uint32_t u[BP_NC][W], s[W], last[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+#pragma unroll
+    for (int c = 0; c < BP_NC; ++c) u[c][w] = a.U[(((size_t)tile * BP_NC + c) * W + w) * 64 + sl];
+    s[w] = a.S[((size_t)tile * W + w) * 64 + sl];
+    last[w] = a.LAST[((size_t)tile * W + w) * 64 + sl];
+  }
+  Rows<K> R;
+  clear_rows<K>(R);
+#pragma unroll
+  for (int l = 1; l <= K; ++l)                          // rows l>=1 begin with l prefix bits (shift_and_inexact.cc:162-164)
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const uint32_t iv = a.INIT[(((size_t)tile * (K > 0 ? K : 1) + (l - 1)) * W + w) * 64 + sl];
+      R.r[l][w] = at0 ? iv : 0u;
+    }
+  const uint32_t str_base = a.lane_first[(size_t)tile * 64 + sl];
+
+  const int64_t upper = a.sub_len + a.halo;
+  for (int64_t o = 0; o < upper; o += 16) {
+    if (__ballot(o < nchar) == 0) break;               // every lane of the wave is through
+    const int64_t off = start + o;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (o < nchar) {
+      if (off + 16 <= a.n) __builtin_memcpy(v, a.text + off, 16);
+      else for (int b = 0; b < 16; ++b) if (off + b < a.n) v[b >> 2] |= (uint32_t)a.text[off + b] << (8 * (b & 3));
+    }
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+      const uint32_t word = b < 4 ? v[0] : (b < 8 ? v[1] : (b < 12 ? v[2] : v[3]));
+      const uint32_t cls = s_cmap[(word >> (8 * (b & 3))) & 0xffu];
+      uint32_t uc[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        uint32_t x = 0u;
+#pragma unroll
+        for (int c = 0; c < BP_NC; ++c) x = cls == (uint32_t)c ? u[c][w] : x;
+        uc[w] = x;                                       // class BP_NC (no pattern has it) and EOS: no mask row
+      }
+      step<K, INDELS, true>(R, uc, s);
+      if (cls > (uint32_t)BP_NC) clear_rows<K>(R);       // EOS code
+      uint32_t hit = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) hit |= R.r[K][w] & last[w];
+      const int64_t t = off + b;
+      if (hit != 0 && o + b < nchar && t >= own_lo) {
+        uint32_t running = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          uint32_t hb = R.r[K][w] & last[w];
+          while (hb) {
+            const int bit = __ffs(hb) - 1;
+            hb &= hb - 1;
+            const uint32_t rank = running + __popc(last[w] & ((1u << bit) - 1u));
+            int lvl = K;                               // shift_and_inexact.cc:323-328
+#pragma unroll
+            for (int l = K - 1; l >= 0; --l) {
+              if (lvl == l + 1 && ((R.r[l][w] >> bit) & 1u)) lvl = l;
+            }
+            const unsigned long long idx = atomicAdd(a.counter, 1ull);
+            if (idx < a.cap) {
+              pm_hit h;
+              h.end = t + 1; h.pid = a.pid_of[str_base + rank]; h.k = (uint8_t)lvl;
+              h.aux[0] = h.aux[1] = h.aux[2] = 0;
+              a.out[idx] = h;
+            }
+          }
+          running += __popc(last[w]);
+        }
+      }
+    }
+  }
+}
+
+template <int K, bool INDELS>
+hipError_t launch_tp(const BitparArgs &a, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((pm_bitpar_scan_tp<K, INDELS>), dim3(blocks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 template <int K, bool INDELS>
 hipError_t launch_t(const BitparArgs &a, int blocks, hipStream_t st) {
   hipLaunchKernelGGL((pm_bitpar_scan<K, INDELS>), dim3(blocks), dim3(256), 0, st, a);
@@ -270,6 +383,7 @@ std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uin
     bit += L;
   }
   const int nlanes = pats.empty() ? 0 : lane + 1;
+  t.nlanes = nlanes;
   t.ntiles = (nlanes + 63) / 64;
   const size_t T = (size_t)t.ntiles;
   t.U.assign(T * BP_NC * W * 64, 0);
@@ -305,7 +419,7 @@ std::string bitpar_build(const std::vector<Pattern> &pats, const std::vector<uin
 
 hipError_t bitpar_upload(const BitparTables &t, bool indels, BitparDevice *d, hipStream_t st) {
   bitpar_free(d);
-  d->ntiles = t.ntiles; d->k = t.k; d->maxlen = t.maxlen; d->indels = indels;
+  d->ntiles = t.ntiles; d->nlanes = t.nlanes; d->k = t.k; d->maxlen = t.maxlen; d->indels = indels;
   auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes ? bytes : 4);
     if (e != hipSuccess) return e;
@@ -328,9 +442,33 @@ void bitpar_free(BitparDevice *d) {
   *d = BitparDevice();
 }
 
+// pattern strings up to which the text-parallel form is the faster one (its cost grows with the
+// strings, the tile form's floor is one pass with 64 strings per wave)
+constexpr int BP_TP_MAX_STRINGS = 32;
+constexpr int64_t BP_TP_SUB = 4096;
+
+static bool bitpar_text_parallel(const BitparDevice &d) {
+  if (const char *env = getenv("PM_BITPAR_TP")) return atoi(env) != 0 && d.nlanes > 0;
+  return d.nlanes > 0 && d.nlanes <= BP_TP_MAX_STRINGS;
+}
+
 ScanGeometry bitpar_geometry(const BitparDevice &d, int64_t begin, int64_t end) {
   ScanGeometry g;
   const int64_t range = std::max<int64_t>(end - begin, 1);
+  if (bitpar_text_parallel(d)) {
+    int64_t sub = BP_TP_SUB;
+    while (sub > 256 && range / (64 * sub) < 1024) sub >>= 1;      // small ranges: still enough waves
+    if (const char *env = getenv("PM_BITPAR_SEGLEN")) {             // test knob: force tiny runs
+      const int64_t v = atoll(env);
+      if (v >= 16) sub = round_up(v, 16);
+    }
+    g.seg_len = 64 * sub;
+    const int64_t s_lo = begin / g.seg_len, s_hi = (end - 1) / g.seg_len;
+    g.nseg = end > begin ? (int)(s_hi - s_lo + 1) : 0;
+    g.threads = 256;
+    g.blocks = (int)(((int64_t)g.nseg * d.nlanes + 3) / 4);
+    return g;
+  }
   // enough waves to fill 256 CUs several times over, but segments long enough that the
   // 256-byte halo each one re-reads stays small
   const int64_t target_waves = 32768;
@@ -362,6 +500,20 @@ hipError_t bitpar_launch(const BitparDevice &d, const uint8_t *d_text, int64_t n
   a.U = d.U; a.S = d.S; a.LAST = d.LAST; a.INIT = d.INIT; a.lane_first = d.lane_first; a.pid_of = d.pid_of;
   a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   const int key = d.k * 2 + (d.indels ? 1 : 0);
+  a.nstr = d.nlanes; a.sub_len = g.seg_len / 64;
+  if (bitpar_text_parallel(d)) {
+    a.halo = (int)round_up(d.maxlen + d.k, 16);
+    switch (key) {
+      case 0: case 1: return launch_tp<0, false>(a, g.blocks, st);
+      case 2: return launch_tp<1, false>(a, g.blocks, st);
+      case 3: return launch_tp<1, true>(a, g.blocks, st);
+      case 4: return launch_tp<2, false>(a, g.blocks, st);
+      case 5: return launch_tp<2, true>(a, g.blocks, st);
+      case 6: return launch_tp<3, false>(a, g.blocks, st);
+      case 7: return launch_tp<3, true>(a, g.blocks, st);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (key) {
     case 0: case 1: return launch_t<0, false>(a, g.blocks, st);
     case 2: return launch_t<1, false>(a, g.blocks, st);

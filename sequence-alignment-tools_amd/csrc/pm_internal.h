@@ -34,6 +34,7 @@ constexpr int BP_BLOCK = 256;      // text bytes per block step (64 lanes x 4 by
 
 struct BitparTables {              // host-built, then uploaded
   int ntiles = 0;                  // 64 lanes per tile
+  int nlanes = 0;                  // lanes (256-bit pattern strings) in use, packed from lane 0 of tile 0
   int k = 0;
   int maxlen = 0;
   int nclasses = 0;                // pattern codes in use (<= BP_NC)
@@ -49,7 +50,7 @@ struct BitparTables {              // host-built, then uploaded
 struct BitparDevice {
   uint32_t *U = nullptr, *S = nullptr, *LAST = nullptr, *INIT = nullptr, *lane_first = nullptr, *pid_of = nullptr;
   uint8_t  *cmap = nullptr;
-  int ntiles = 0, k = 0, maxlen = 0;
+  int ntiles = 0, nlanes = 0, k = 0, maxlen = 0;
   bool indels = false;
 };
 
