@@ -455,7 +455,7 @@ __device__ __forceinline__ bool edits_plausible(const SeedArgs &a, int64_t p, ui
     const uint64_t z = x | (x >> 2) | (x >> 4) | (x >> 6);
     M |= ~(z | (z >> 1));
   }
-  return __popcll(M & 0x155555555ull) >= 17 - 4 * k;               // words j = 0..16 at bits 2j
+  return (int)__popcll(M & 0x155555555ull) >= 17 - 4 * k;               // words j = 0..16 at bits 2j
 }
 
 __device__ __forceinline__ pm_hit edit_record(int64_t end, uint32_t pid, uint32_t lvl1) {
