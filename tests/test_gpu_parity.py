@@ -637,3 +637,24 @@ def test_mixed_pattern_set_splits_between_engines():
     pm.init(codes, table)
     assert pm.selected()[1] == sat_amd.KERNEL_BITPAR
     pm.close()
+
+
+def test_large_hit_lists_come_back_sorted():
+    """(end, pid, k) order of a hit list large enough for the sliced, threaded sort (pm_api.cpp
+    sort_hits), incl. many equal ends and a skewed distribution of ends."""
+    rng = np.random.default_rng(31)
+    pm = sat_amd.PatternMatch(k=0)
+    pm.add_pattern("ACGTACGTACGTACGTACGT", 1)
+    pm.init(np.frombuffer(b"\nACGTACGTACGTACGTACGTAC\n", dtype=np.uint8).copy())
+    n = 300_000
+    for ends in (rng.integers(1, 1 << 33, size=n), rng.integers(1, 5000, size=n),
+                 np.concatenate([rng.integers(1, 100, size=n - 10), rng.integers(1 << 35, 1 << 36, size=10)])):
+        c = np.zeros(n, dtype=sat_amd.HIT_DTYPE)
+        c["end"] = ends
+        c["pid"] = rng.integers(1, 1000, size=n)
+        c["k"] = rng.integers(0, 3, size=n)
+        got = pm.finalize(c, 1 << 40, last=True, sort=True)          # keyword_tree: pass-through, then the sort
+        order = np.lexsort((c["k"], c["pid"], c["end"]))
+        assert got.size == n
+        assert (got["end"] == c["end"][order]).all() and (got["pid"] == c["pid"][order]).all() and (got["k"] == c["k"][order]).all()
+    pm.close()
