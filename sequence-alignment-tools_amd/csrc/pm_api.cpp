@@ -107,6 +107,8 @@ struct pm_handle {
   uint8_t *d_fpat_len = nullptr;
   uint32_t *d_fpat_id = nullptr;
   // exact_halves rule on the device: payload arrays and the pair sort's workspace
+  uint32_t *d_packed = nullptr;       // the stream at 2 bits per base (seed family's first stage), rebuilt by every pm_init
+  size_t packed_cap = 0;
   pm_hit *d_carry = nullptr;          // carried candidates of an earlier range, uploaded for the device clustering
   size_t d_carry_cap = 0;
   uint32_t *d_vals = nullptr, *d_vals_alt = nullptr;
@@ -197,7 +199,8 @@ static void free_device(pm_handle *h) {
   if (h->d_wlen) (void)hipFree(h->d_wlen);
   if (h->d_woff) (void)hipFree(h->d_woff);
   if (h->d_wout) (void)hipFree(h->d_wout);
-  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id, h->d_vals, h->d_vals_alt, h->d_htemp, h->d_carry};
+  void *fw[] = {h->d_keys, h->d_keys_alt, h->d_ctemp, h->d_fout, h->d_fleft, h->d_fcounts, h->d_fpat_len, h->d_fpat_id, h->d_vals, h->d_vals_alt, h->d_htemp, h->d_carry, h->d_packed};
+  h->d_packed = nullptr; h->packed_cap = 0;
   h->d_vals = h->d_vals_alt = nullptr; h->d_htemp = nullptr; h->vals_cap = 0; h->htemp_bytes = 0; h->d_carry = nullptr; h->d_carry_cap = 0;
   for (void *q : fw) if (q) (void)hipFree(q);
   if (h->h_fcounts) (void)hipHostFree(h->h_fcounts);
@@ -511,6 +514,21 @@ static hipError_t upload_stream(int device, void *d, const uint8_t *text, size_t
   return hipSuccess;
 }
 
+// The seed family's first stage reads the stream at 2 bits per base (pm_seed.hip pack_stream): one
+// pass over the stream per pm_init, on the handle's stream, after the bytes are in HBM.
+static int ensure_packed(pm_handle *h) {
+  if (h->kern != PM_KERNEL_SEED) return PM_OK;
+  const size_t words = (size_t)((h->n + 15) / 16);
+  if (!h->d_packed || h->packed_cap < words) {
+    if (h->d_packed) (void)hipFree(h->d_packed);
+    h->d_packed = nullptr;
+    h->packed_cap = words;
+    HIP_TRY(h, hipMalloc((void **)&h->d_packed, (words + 4) * sizeof(uint32_t)));
+  }
+  HIP_TRY(h, pack_stream(h->d_text, h->n, h->sd.ascii, h->d_packed, (int64_t)words, h->stream));
+  return PM_OK;
+}
+
 extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8_t *table, int32_t table_len) {
   if (!h || (!text && n > 0) || n < 0) return fail(h, PM_E_INVALID, "pm_init: bad arguments");
   const double ti0 = now_ms();
@@ -541,7 +559,8 @@ extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8
   if (copier.joinable()) copier.join();
   if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] init: runtime + stream buffer %.0f ms, tables %.0f ms, then %.0f ms more for the stream upload\n", ti1 - ti0, ti2 - ti1, now_ms() - ti2);
   if (copy_err != hipSuccess) return fail(h, PM_E_HIP, std::string("pm_init: stream upload: ") + hipGetErrorString(copy_err));
-  return rc;
+  if (rc) return rc;
+  return ensure_packed(h);
 }
 
 extern "C" int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *table, int32_t table_len,
@@ -552,7 +571,9 @@ extern "C" int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const
   if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
   h->d_text = (const uint8_t *)d_text; h->own_d_text = false; h->h_text = nullptr; h->n = n;
   h->stream = (hipStream_t)hip_stream;
-  return init_common(h, table, table_len);
+  const int rc = init_common(h, table, table_len);
+  if (rc) return rc;
+  return ensure_packed(h);
 }
 
 extern "C" int pm_set_capacity(pm_handle *h, size_t max_candidates) {
@@ -625,7 +646,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     for (int t = 0; t < ntiles; ++t) {
       EditStage es; es.d_seeds = h->d_seeds; es.d_seed_count = h->d_seed_count + 1 + t; es.seed_cap = h->seed_cap; es.tile = t;
       const SeedDevice &d = t == 0 ? h->sd : h->sd_more[t - 1];
-      HIP_TRY(h, seed_launch(d, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 ? &h->geo : nullptr, &es));
+      HIP_TRY(h, seed_launch(d, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 ? &h->geo : nullptr, &es));
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->last_launches = 2 * ntiles;
@@ -633,9 +654,9 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   }
   else if (h->kern == PM_KERNEL_SEED)
   {
-    HIP_TRY(h, seed_launch(h->sd, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
+    HIP_TRY(h, seed_launch(h->sd, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, &h->geo));
     for (SeedDevice &d : h->sd_more)
-      HIP_TRY(h, seed_launch(d, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr));
+      HIP_TRY(h, seed_launch(d, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr));
     h->last_launches = 1 + (int)h->sd_more.size();
     if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }

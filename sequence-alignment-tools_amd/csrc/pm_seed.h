@@ -74,7 +74,9 @@ struct EditStage {
   uint64_t seed_cap = 0;
   int tile = 0;
 };
-hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
+// 2-bit form of the stream for the scan kernels' first stage: d_packed holds (n + 15) / 16 dwords
+hipError_t pack_stream(const uint8_t *d_text, int64_t n, bool ascii, uint32_t *d_packed, int64_t npacked, hipStream_t st);
+hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
                        ScanGeometry *geo_out, const EditStage *es = nullptr);
 

@@ -77,6 +77,8 @@ struct SeedArgs {
                                         // partner's stream window is known before the half's record is read
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
   const uint8_t *part_len, *part_side;  // its length; 0 = partner lies to the right of the seed, 1 = to the left
+  const uint32_t *packed;               // the stream, 2 bits per base, 16 bases per dword (pack_stream); the first stage reads this
+  int64_t npacked;                      // dwords in `packed`
   const SeedArgs *self;                 // device copy of this struct, for the out-of-line rare paths
 };
 
@@ -115,6 +117,15 @@ __device__ __forceinline__ uint4 load16(const uint8_t *text, int64_t off, int64_
     return *reinterpret_cast<const uint4 *>(text + off);
   }
   return load16_edge(text, off, n);
+}
+
+// One dword of the 2-bit packed stream = the 16 bases from `pos` (a multiple of 16) on; zero
+// outside the stream, like the bytes load16_edge hands out.
+template <bool NT>
+__device__ __forceinline__ uint32_t load_packed(const uint32_t *packed, int64_t npacked, int64_t pos) {
+  const int64_t i = pos >> 4;
+  if (pos < 0 || i >= npacked) return 0u;
+  return NT ? __builtin_nontemporal_load(packed + i) : packed[i];
 }
 
 // Hash of the combo's part of a window.  MODE 0: any piece layout (mask + fold + multiply);
@@ -587,12 +598,10 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo], sel = a.perm_sel[combo];
   const uint4 *buckets = a.buckets + (size_t)combo * 2 * ((size_t)1 << (32 - a.bucket_shift));
   const uint32_t *bitmap2 = a.bitmap2 + (size_t)combo * ((size_t)1 << (a.lb2 - 5));
-  const int sh = a.ascii ? 1 : 0;
   // the 32 bases in front of the wave's range
   uint32_t carry1, carry2;
   {
-    const uint4 v = load16<MODE == 2>(a.text, ws - 32 + 16 * (lane & 1), a.n);
-    const uint32_t pk = pack16(v, sh);
+    const uint32_t pk = load_packed<MODE == 2>(a.packed, a.npacked, ws - 32 + 16 * (lane & 1));
     carry2 = __builtin_amdgcn_readlane(pk, 0);
     carry1 = __builtin_amdgcn_readlane(pk, 1);
   }
@@ -777,17 +786,15 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     qn = 0;
   };
 
-  // four 1-KiB blocks of the stream in flight per wave (64 KiB per CU): rolling prefetch ring
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  uint4 q0 = load16<MODE == 2>(a.text, ws + 16 * lane, a.n);
-  uint4 q1 = ws + 1024 < own_hi ? load16<MODE == 2>(a.text, ws + 1024 + 16 * lane, a.n) : zero4;
-  uint4 q2 = ws + 2048 < own_hi ? load16<MODE == 2>(a.text, ws + 2048 + 16 * lane, a.n) : zero4;
-  uint4 q3 = ws + 3072 < own_hi ? load16<MODE == 2>(a.text, ws + 3072 + 16 * lane, a.n) : zero4;
+  // four blocks of 1024 bases (one packed dword per lane each) in flight per wave: rolling prefetch ring
+  uint32_t q0 = load_packed<MODE == 2>(a.packed, a.npacked, ws + 16 * lane);
+  uint32_t q1 = ws + 1024 < own_hi ? load_packed<MODE == 2>(a.packed, a.npacked, ws + 1024 + 16 * lane) : 0u;
+  uint32_t q2 = ws + 2048 < own_hi ? load_packed<MODE == 2>(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
+  uint32_t q3 = ws + 3072 < own_hi ? load_packed<MODE == 2>(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
   for (int64_t bb = ws; bb < own_hi; bb += 1024) {
-    const uint4 v = q0;
+    const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
-    if (bb + 4096 < own_hi) q3 = load16<MODE == 2>(a.text, bb + 4096 + 16 * lane, a.n);
-    const uint32_t cur = pack16(v, sh);
+    if (bb + 4096 < own_hi) q3 = load_packed<MODE == 2>(a.packed, a.npacked, bb + 4096 + 16 * lane);
     uint32_t prev1 = __shfl_up(cur, 1), prev2 = __shfl_up(cur, 2);
     if (lane == 0) { prev1 = carry1; prev2 = carry2; }
     if (lane == 1) prev2 = carry1;
@@ -961,7 +968,25 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
   if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
 }
 
+// The stream at 2 bits per base, made once per pm_init (a re-encoding of the database like the
+// reference's compress_seq output formats, not part of a scan): dword i = bases 16i .. 16i+15,
+// base j in bits 2j, codes as pack4 derives them (A,C,G,T exact; any other byte aliases to one of
+// them and is weeded out where the full characters are compared).
+__global__ void pm_pack_stream(const uint8_t *text, int64_t n, int sh, uint32_t *packed, int64_t npacked) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= npacked) return;
+  packed[i] = pack16(load16<true>(text, 16 * i, n), sh);
+}
+
 }  // namespace
+
+hipError_t pack_stream(const uint8_t *d_text, int64_t n, bool ascii, uint32_t *d_packed, int64_t npacked, hipStream_t st) {
+  if (npacked <= 0) return hipSuccess;
+  const int threads = 256;
+  hipLaunchKernelGGL(pm_pack_stream, dim3((unsigned)((npacked + threads - 1) / threads)), dim3(threads), 0, st,
+                     d_text, n, ascii ? 1 : 0, d_packed, npacked);
+  return hipGetLastError();
+}
 
 // ---- host side: plan, tables, launch ------------------------------------------------------------
 
@@ -1280,15 +1305,17 @@ ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end) {
   return g;
 }
 
-hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, int64_t n, int64_t begin, int64_t end,
+hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, hipStream_t st,
                        ScanGeometry *geo_out, const EditStage *es) {
+  if (!d_packed) return hipErrorInvalidValue;
   if (end > n) end = n;
   ScanGeometry g = seed_geometry(d, begin, end);
   if (geo_out) *geo_out = g;
   if (g.blocks <= 0 || d.nslots == 0) return hipSuccess;
   SeedArgs a;
   a.text = d_text; a.n = n; a.begin = begin; a.end = end;
+  a.packed = d_packed; a.npacked = (n + 15) / 16;
   a.chunk_len = g.seg_len; a.chunk0 = (d.edits && begin > d.edits ? begin - d.edits : (d.edits ? 0 : begin)) / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;                                                   // one run ~ one chunk per CU
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
