@@ -395,7 +395,9 @@ def main():
                                    % (args.primers, args.length, len(allp), "-k" if args.indels else "-K", args.k,
                                       ("%.3g" % (shard / 1e9)), world, args.entries),
                        "semantics": pm.selected()[0], "kernel_family": pm.selected()[1], "kernel": desc,
-                       "final_hits": final_hits[0], "candidates": cand_count[0]},
+                       "final_hits": final_hits[0], "candidates": cand_count[0],
+                       "stream": "1 B/base resident in HBM before the timed region; the handle's init (untimed, with the pattern tables) "
+                                 "also derives its 2-bit form, which the seed kernels' first stage reads"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, shard),
                          "kernel_ms": kms, "algorithmic_bytes": alg_bytes},
