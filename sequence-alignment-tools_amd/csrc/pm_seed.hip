@@ -102,6 +102,9 @@ __device__ __noinline__ uint4 load16_edge(const uint8_t *text, int64_t off, int6
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+#ifndef PM_TESTS_GROUP
+#define PM_TESTS_GROUP 8
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte stream load.  NT (single-combo plans: the stream is read exactly once) marks it
@@ -819,14 +822,15 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
     // first stage, parts 1 and 2 for one displacement pattern (sa, sb = displacement of the combo's
     // first and second piece; compile-time constants at every call): 16 hashes, 16 LDS reads in
     // flight, three bit tests per window, verdicts funnelled into one register
+    constexpr int TG = PM_TESTS_GROUP;
     auto tests = [&](int sa, int sb) __attribute__((always_inline)) -> uint32_t {
       uint32_t acc = 0;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {                        // eight reads in flight, then their eight verdicts
-        uint32_t hs[8], wd[8];
+      for (int half = 0; half < 16 / TG; ++half) {                   // TG reads in flight, then their TG verdicts
+        uint32_t hs[TG], wd[TG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = 8 * half + j;
+        for (int j = 0; j < TG; ++j) {
+          const int i = TG * half + j;
           uint32_t wlo, whi;
           window(i, prev2, prev1, cur, wlo, whi);
           if (EDITS && (sa != 0 || sb != 0)) {
@@ -847,10 +851,10 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
         __builtin_amdgcn_sched_barrier(0);                          // without it the scheduler waits for every read by itself
         if (HALVES && MODE == 0 && exact) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_alignbit(wd[j] >> (hs[j] & 31u), acc, 1);
+          for (int j = 0; j < TG; ++j) acc = __builtin_amdgcn_alignbit(wd[j] >> (hs[j] & 31u), acc, 1);
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_alignbit(bloom_test(wd[j], hs[j]), acc, 1);
+          for (int j = 0; j < TG; ++j) acc = __builtin_amdgcn_alignbit(bloom_test(wd[j], hs[j]), acc, 1);
         }
       }
       return (acc >> 16) & own;
