@@ -1295,7 +1295,12 @@ void seed_free(SeedDevice *d) {
 
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end) {
   ScanGeometry g;
-  int64_t chunk = 1 << 19;                                         // 512 KiB per workgroup
+  int64_t chunk = 1 << 19;                                         // 512 Ki positions per workgroup
+  // ten-combo substitution plans: 2 Mi positions per workgroup amortise the 128 KiB filter staging and
+  // the pipeline fill/drain over four times the work (-K 2, 3 Gbp: 26.6 -> 25.2 ms) while the grid
+  // still has dozens of workgroups per CU; the one- and four-combo plans and the edit-distance plan
+  // measured no gain or a loss (sweep in DESIGN.md section 7)
+  if (!d.edits && !d.halves && d.ncombos >= 8 && (end - begin) / ((int64_t)1 << 21) * d.ncombos >= 256 * 16) chunk = (int64_t)1 << 21;
   if (const char *env = getenv("PM_SEED_CHUNK")) {                 // test knob
     const int64_t v = atoll(env);
     if (v >= 1024 * WAVES) chunk = v / (1024 * WAVES) * (1024 * WAVES);
