@@ -61,13 +61,15 @@ def gen_stream(lo, hi, total, entries, seed, device):
 
 def make_primers(stream0, n_primers, L, seed):
     """90 % i.i.d. random 20-mers, 10 % sampled from the database and given 0/1/2 substitutions
-    (SURVEY 8d).  Returns list of str."""
+    (SURVEY 8d).  Returns (list of str, planted) with planted = [(primer index, stream index of the
+    site's first base, Hamming distance of the primer to the site)]."""
     rng = np.random.default_rng(seed)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     pri = rng.integers(0, 4, size=(n_primers, L), dtype=np.uint8)
     n_pl = n_primers // 10
     host = stream0.cpu().numpy()
     placed = 0
+    planted = []
     while placed < n_pl:
         a = int(rng.integers(1, host.size - L - 1))
         w = host[a:a + L]
@@ -78,8 +80,9 @@ def make_primers(stream0, n_primers, L, seed):
             i = int(rng.integers(0, L))
             w[i] = (w[i] + 1 + int(rng.integers(0, 3))) % 4
         pri[placed] = w
+        planted.append((placed, a, int((w != host[a:a + L]).sum())))
         placed += 1
-    return [lut[r].tobytes().decode() for r in pri]
+    return [lut[r].tobytes().decode() for r in pri], planted
 
 
 class CudaArray:
@@ -196,7 +199,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="bases for the CPU baseline (0 = auto, -1 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the one-reference-process-per-core figure")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the all-cores figure (0 = min(cores, 16))")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the all-cores figure (0 = every host core)")
+    ap.add_argument("--dump-hits", default="", help="rank 0 writes the final hits of the last step (global stream indices, sorted) to this .npy file")
+    ap.add_argument("--capacity", type=int, default=0, help="initial record capacity (0 = default; small values exercise the grow-and-rescan path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,8 +235,11 @@ def main():
     ghi = min(total, hi + GUARD + HALO)
     stream = gen_stream(glo, ghi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev)
     n_bases_total = total - (args.entries * (world if args.scaling == "weak" else 1) + 1)
+    planted = []
     if rank == 0:
-        primers = make_primers(stream[:min(stream.numel(), 1 << 26)], args.primers, args.length, 7)
+        # sampled from a prefix every launch geometry holds on rank 0 (so that 1 and N ranks of a
+        # --scaling strong run search the same primers)
+        primers, planted = make_primers(stream[:min(stream.numel(), 1 << 26, max(total // 8, 1 << 16))], args.primers, args.length, 7)
     else:
         primers = None
     if world > 1:
@@ -248,7 +256,7 @@ def main():
     t0 = time.time()
     pm.init_device(stream.data_ptr(), stream.numel(), TABLE, stream=torch.cuda.current_stream().cuda_stream, keepalive=stream)
     # record buffer: the edit-distance seed plan reports a candidate through several seeds before its dedup
-    pm.set_capacity(1 << 28 if (args.indels and args.k >= 2) else 1 << 24)
+    pm.set_capacity(args.capacity if args.capacity > 0 else (1 << 28 if (args.indels and args.k >= 2) else 1 << 24))
     log("index build %.2f s; semantics=%s kernel=%s" % (time.time() - t0, *pm.selected()))
     begin, end = lo - glo, hi - glo
 
@@ -260,6 +268,8 @@ def main():
     kernel_ms = []
     final_hits = [0]
     cand_count = [0]
+    rescans = [0]
+    last_final = [None]                                             # rank 0: final hits of the last step (host array or pinned int64 pairs)
 
     # host landing zone for final hits (pinned: the copy out of HBM is part of every step)
     out_pin = torch.empty((1 << 24) * 16, dtype=torch.uint8, pin_memory=True)
@@ -272,6 +282,49 @@ def main():
     all_pin = torch.empty((1 << 24) * 2 * (world if own_path else 1), dtype=torch.int64, pin_memory=True) if rank == 0 and own_path else None
     dev_final = [True]                                              # GPU clustering available for this option set?
 
+    def scan(lo_, hi_):
+        """Device stage.  Returns (count, 0), or (0, needed capacity) when the record buffer was too
+        small (the caller grows it and scans again -- on every rank, so that no rank waits in a
+        collective for one that raised)."""
+        pm.scan_async(lo_, hi_)
+        try:
+            ncand = pm.scan_wait()
+        except sat_amd.PmError as e:
+            if e.code != sat_amd.PM_E_OVERFLOW:
+                raise
+            return 0, max(int(e.required), 1)
+        ms, _ = pm.last_kernel_time()
+        kernel_ms.append(ms)
+        return ncand, 0
+
+    def grow(need):
+        rescans[0] += 1
+        pm.set_capacity(int(need * 1.25) + 1024)
+
+    def exchange_counts(cnt, need):
+        """all_gather of the ranks' record counts; a rank whose scan overflowed sends -1.  Returns the
+        counts, or None when some rank has to scan again (then every rank does)."""
+        mine = torch.tensor([-1 if need else cnt], dtype=torch.int64, device=cdev)
+        clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(clist, mine)
+        cl = torch.cat(clist).tolist()                                  # one host sync for all counts
+        if min(cl) < 0:
+            if need:
+                grow(need)
+            return None
+        return cl
+
+    def records_for_gather(ptr, cnt, mx):
+        """this rank's records as the padded int64 buffer the gather sends: straight out of HBM with
+        RCCL; through host memory only in the gloo rehearsal (its transport is the host)"""
+        pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)
+        if cnt:
+            if cdev.type == "cuda":
+                pad[:cnt * 2].copy_(torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).view(torch.int64))
+            else:
+                pad[:cnt * 2] = torch.from_numpy(pm.copy_records(ptr, cnt).view(np.int64).reshape(-1))
+        return pad
+
     def finalize_rank0(ptr, cnt, scanned_to):
         """records in HBM -> final hits on the host of rank 0"""
         if dev_final[0]:
@@ -283,28 +336,22 @@ def main():
                 dev_final[0] = False
         if world > 1 and pm.selected()[1] == sat_amd.KERNEL_BITPAR and pm.selected()[0] in (sat_amd.SEM_EXACT_HALVES, sat_amd.SEM_EXACT_BASES, sat_amd.SEM_FILTER_BITVEC) and args.indels:
             raise SystemExit("bench.py --gpus>1: this option set verifies on the host with stream text, which rank 0 does not hold (DESIGN.md 5)")
-        cands = np.zeros(cnt, dtype=sat_amd.HIT_DTYPE)
-        if cnt:
-            cands = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).cpu().numpy().view(sat_amd.HIT_DTYPE)
+        cands = pm.copy_records(ptr, cnt)
         pm.reset()
         return pm.finalize(cands, scanned_to, last=True, sort=False)
 
     def step_owned():
-        pm.scan_async(g_lo, g_hi)
-        ncand = pm.scan_wait()
-        ms, _ = pm.last_kernel_time()
-        kernel_ms.append(ms)
-        mine_hits = pm.finalize_device(0, sort=False, out=out_buf, owned=(begin, end, g_lo, None if ghi == total else g_hi))
-        cnt = mine_hits.size
-        # the path's one exchange: final hit records to rank 0 over xGMI
-        mine = torch.tensor([cnt], dtype=torch.int64, device=cdev)
-        clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
-        dist.all_gather(clist, mine)
-        cl = torch.cat(clist).tolist()                                  # one host sync for all counts
-        mx = max(max(cl), 1)
-        pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)
-        if cnt:
-            pad[:cnt * 2].copy_(out_pin[:cnt * 16].view(torch.int64), non_blocking=True)
+        while True:
+            ncand, need = scan(g_lo, g_hi)
+            ptr, cnt = (0, 0)
+            if not need:
+                # sort, clustering (and for -k the cluster DPs) on this rank's GPU; the final hits stay in HBM
+                ptr, cnt = pm.finalize_device(0, sort=False, owned=(begin, end, g_lo, None if ghi == total else g_hi), keep=True)
+            # the path's one exchange: final hit records to rank 0 over xGMI
+            cl = exchange_counts(cnt, need)
+            if cl is not None:
+                break
+        pad = records_for_gather(ptr, cnt, max(max(cl), 1))
         gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, gathered, dst=0)
         if rank == 0:
@@ -326,29 +373,31 @@ def main():
                 torch.cuda.synchronize()
             cand_count[0] = at // 2
             final_hits[0] = at // 2
+            last_final[0] = all_pin[:at]
         return ncand
 
     def step():
         if own_path:
             return step_owned()
-        pm.scan_async(begin, end)
-        ncand = pm.scan_wait()
-        ms, _ = pm.last_kernel_time()
-        kernel_ms.append(ms)
-        ptr, cnt = pm.candidates_device()
         if world == 1:
+            while True:
+                ncand, need = scan(begin, end)
+                if not need:
+                    break
+                grow(need)
+            ptr, cnt = pm.candidates_device()
             cand_count[0] = cnt
-            final_hits[0] = finalize_rank0(ptr, cnt, end).size
+            last_final[0] = finalize_rank0(ptr, cnt, end)
+            final_hits[0] = last_final[0].size
             return ncand
-        # the path's one real exchange: variable-length hit records to rank 0 over xGMI
-        mine = torch.tensor([cnt], dtype=torch.int64, device=cdev)
-        clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
-        dist.all_gather(clist, mine)
-        cl = [int(x.item()) for x in clist]
-        mx = max(max(cl), 1)
-        pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)   # a record = two int64 words
-        if cnt:
-            pad[:cnt * 2] = torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).view(torch.int64).to(cdev)
+        while True:
+            ncand, need = scan(begin, end)
+            ptr, cnt = (0, 0) if need else pm.candidates_device()
+            # the path's one real exchange: variable-length hit records to rank 0 over xGMI
+            cl = exchange_counts(cnt, need)
+            if cl is not None:
+                break
+        pad = records_for_gather(ptr, cnt, max(max(cl), 1))   # a record = two int64 words
         gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, gathered, dst=0)
         if rank == 0:
@@ -362,7 +411,8 @@ def main():
             tot = allrec.shape[0]
             cand_count[0] = tot
             scanned = int(total)
-            final_hits[0] = finalize_rank0(allrec.data_ptr(), tot, scanned).size
+            last_final[0] = finalize_rank0(allrec.data_ptr(), tot, scanned)
+            final_hits[0] = last_final[0].size
         return ncand
 
     for _ in range(args.warmup):
@@ -378,6 +428,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    found_planted = None
+    if rank == 0 and last_final[0] is not None:
+        torch.cuda.synchronize()
+        lf = last_final[0]
+        fin = (lf.numpy().view(sat_amd.HIT_DTYPE) if isinstance(lf, torch.Tensor) else lf).copy()
+        fin = fin[np.lexsort((fin["k"], fin["pid"], fin["end"]))]
+        if args.dump_hits:
+            np.save(args.dump_hits, fin)
+        # every planted site within reach (distance <= k) must be reported: primer i (forward strand,
+        # id i+1) with at most its planted distance, at the site's end -- filter_bitvec reports one hit
+        # per chain of candidates and exact_halves drops hits within 2k of the last kept one, so the
+        # reported end may sit up to 2k+1 from the planted one
+        if planted and not args.odd:
+            tol = 2 * args.k + 1
+            key = fin["pid"].astype(np.int64) << 40 | fin["end"]
+            order = np.argsort(key)
+            key, kk = key[order], fin["k"][order]
+            want = [(i, a, d) for (i, a, d) in planted if d <= args.k]
+            found_planted = 0
+            for (i, a, d) in want:
+                e = a + args.length
+                lo_i = np.searchsorted(key, ((i + 1) << 40) | max(0, e - tol))
+                hi_i = np.searchsorted(key, ((i + 1) << 40) | (e + tol), side="right")
+                if hi_i > lo_i and kk[lo_i:hi_i].min() <= d:
+                    found_planted += 1
+            planted = want
+            if found_planted != len(planted):
+                raise SystemExit("bench.py: only %d of %d planted primer sites were reported" % (found_planted, len(planted)))
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n_bases_total / (dt / args.steps) / 1e9
@@ -390,12 +468,15 @@ def main():
             "metric": baseline_metric(),
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "pack_ms": pm.pack_time(),
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%d x %d-mer primers, both strands (%d patterns), %s %d, %s Gbp stream per GPU x %d GPU(s), %d entries"
                                    % (args.primers, args.length, len(allp), "-k" if args.indels else "-K", args.k,
                                       ("%.3g" % (shard / 1e9)), world, args.entries),
                        "semantics": pm.selected()[0], "kernel_family": pm.selected()[1], "kernel": desc,
                        "final_hits": final_hits[0], "candidates": cand_count[0],
+                       "planted_found": None if found_planted is None else "%d of %d" % (found_planted, len(planted)),
+                       "rescans_after_overflow": rescans[0],
                        "stream": "1 B/base resident in HBM before the timed region; the handle's init (untimed, with the pattern tables) "
                                  "also derives its 2-bit form, which the seed kernels' first stage reads"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -47,7 +47,7 @@ typedef enum {
   PM_E_UNSUPPORTED = -2,   /* valid in the reference, not implemented by this engine (message says what) */
   PM_E_NOMEM = -3,
   PM_E_HIP = -4,           /* HIP runtime error (no device, launch failure, ...) */
-  PM_E_OVERFLOW = -5,      /* candidate buffer too small; *n_out holds the required count */
+  PM_E_OVERFLOW = -5,      /* candidate buffer too small; *n_out holds the required count (> capacity) */
   PM_E_FATAL = -6          /* the reference would timestamp()+exit(1) here (e.g. select.cc:87-90) */
 } pm_status;
 
@@ -161,6 +161,16 @@ int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scan
 int pm_finalize_device_owned(pm_handle *h, const void *d_cands, size_t n, int64_t own_lo, int64_t own_hi,
                              int64_t guard_lo, int64_t guard_hi, int flags, pm_hit *out, size_t cap, size_t *n_out);
 
+/* pm_finalize_device / pm_finalize_device_owned with out == NULL leave the final hits in HBM (the
+ * exchange step of a position-sharded scan gathers them from there: no trip through host memory);
+ * this returns their address and count.  Valid until the next scan or finalize call of the handle.
+ * PM_FINALIZE_SORTED is not available in this form (PM_E_INVALID). */
+int pm_final_hits_device(pm_handle *h, void **d_hits, size_t *n);
+
+/* Copy n 16-byte records from HBM (a pointer obtained from pm_candidates_device /
+ * pm_final_hits_device, or a gather buffer) to host memory on the handle's stream, synchronously. */
+int pm_copy_records(pm_handle *h, const void *d_src, size_t n, pm_hit *out);
+
 /* The caller's per-hit re-alignment (primer_match.cc:1135-1151, pcr_match.cc:1108-1127):
  * exact_alignment::align (pattern_alignment.cc:29-43) for k == 0, otherwise
  * editdist_alignment(key,key,k,eos,wc,tn,indels,dm,esb,eeb,false)::align with traceback
@@ -189,6 +199,11 @@ int pm_describe(const pm_handle *h, char *buf, size_t buflen);
 /* Timing of the scan kernels of the last pm_scan_candidates[_async], measured with HIP events on
  * the handle's stream: milliseconds and number of launches. */
 int pm_last_kernel_time(pm_handle *h, float *ms, int *launches);
+
+/* Duration of the one-off re-encoding of the stream to 2 bits per base that pm_init[_device] runs
+ * for the seed kernel family (0 for the bit-parallel family): not part of a scan, reported so that a
+ * reader can add it to a single cold pass. */
+int pm_pack_time(pm_handle *h, float *ms);
 
 /* pick_pattern_index's automatic choice (select.cc:101-141) without a handle. */
 int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized, int32_t k, int32_t wildcards,

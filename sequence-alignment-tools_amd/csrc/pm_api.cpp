@@ -79,6 +79,7 @@ struct pm_handle {
   unsigned long long *h_counter = nullptr;     // pinned
   size_t cap = 0;
   size_t last_count = 0;
+  size_t overflow_need = 0;           // record count a PM_E_OVERFLOW of the host-added records asks for
   int64_t scan_begin = 0;
   bool scan_pending = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -103,6 +104,9 @@ struct pm_handle {
   void *d_ctemp = nullptr;
   size_t ckeys_cap = 0, ctemp_bytes = 0;
   pm_hit *d_fout = nullptr, *d_fleft = nullptr;
+  const pm_hit *d_final = nullptr;    // final hits left in HBM by a finalize call with out == NULL
+  size_t n_final = 0;
+  float pack_ms = 0.f;                // duration of the last 2-bit re-encoding of the stream (ensure_packed)
   unsigned long long *d_fcounts = nullptr, *h_fcounts = nullptr;
   uint8_t *d_fpat_len = nullptr;
   uint32_t *d_fpat_id = nullptr;
@@ -327,6 +331,11 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   bitpar_free(&h->bp); seed_free(&h->sd);
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
+  // tables pm_finalize_device builds on first use depend on the alphabet mapping and the pattern
+  // list of THIS init: drop the ones of an earlier init
+  { void *lazy[] = {h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_fpat_len, h->d_fpat_id}; for (void *q : lazy) if (q) (void)hipFree(q); }
+  h->d_dp_codes = nullptr; h->d_dp_esb = h->d_dp_eeb = nullptr; h->d_fpat_len = nullptr; h->d_fpat_id = nullptr;
+  h->d_final = nullptr; h->n_final = 0;
   h->seed_flags = false;
   h->start_cached = false; h->start_cache.clear();
   std::string why;
@@ -525,7 +534,11 @@ static int ensure_packed(pm_handle *h) {
     h->packed_cap = words;
     HIP_TRY(h, hipMalloc((void **)&h->d_packed, (words + 4) * sizeof(uint32_t)));
   }
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   HIP_TRY(h, pack_stream(h->d_text, h->n, h->sd.ascii, h->d_packed, (int64_t)words, h->stream));
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  (void)hipEventElapsedTime(&h->pack_ms, h->ev0, h->ev1);
   return PM_OK;
 }
 
@@ -770,7 +783,11 @@ static int stream_start_candidates(pm_handle *h) {
     }
   }
   if (extra.empty()) return PM_OK;
-  if (h->last_count + extra.size() > h->cap) return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)");
+  if (h->last_count + extra.size() > h->cap) {
+    h->overflow_need = h->last_count + extra.size();
+    h->last_count = 0;
+    return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)");
+  }
   HIP_TRY(h, hipMemcpy(h->d_cands + h->last_count, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
   h->last_count += extra.size();
   return PM_OK;
@@ -835,7 +852,7 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   if (h->kern == PM_KERNEL_SEED && h->scan_begin == 0 && h->seed_k > 0 &&
       (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT)) {
     int rc = stream_start_candidates(h);
-    if (rc) return rc;
+    if (rc) { if (rc == PM_E_OVERFLOW && n_out) *n_out = h->overflow_need; return rc; }
     if (n_out) *n_out = h->last_count;
   }
   return PM_OK;
@@ -859,6 +876,27 @@ extern "C" int pm_candidates_device(pm_handle *h, void **d_records, size_t *n) {
   if (!h || !h->inited) return PM_E_INVALID;
   if (d_records) *d_records = h->d_cands;
   if (n) *n = h->last_count;
+  return PM_OK;
+}
+
+extern "C" int pm_pack_time(pm_handle *h, float *ms) {
+  if (!h || !h->inited || !ms) return PM_E_INVALID;
+  *ms = h->kern == PM_KERNEL_SEED ? h->pack_ms : 0.f;
+  return PM_OK;
+}
+
+extern "C" int pm_final_hits_device(pm_handle *h, void **d_hits, size_t *n) {
+  if (!h || !h->inited) return PM_E_INVALID;
+  if (d_hits) *d_hits = const_cast<pm_hit *>(h->d_final);
+  if (n) *n = h->n_final;
+  return PM_OK;
+}
+
+extern "C" int pm_copy_records(pm_handle *h, const void *d_src, size_t n, pm_hit *out) {
+  if (!h || !h->inited || (n && (!d_src || !out))) return fail(h, PM_E_INVALID, "pm_copy_records: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (n) HIP_TRY(h, hipMemcpyAsync(out, d_src, n * sizeof(pm_hit), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return PM_OK;
 }
 
@@ -1287,6 +1325,10 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   if (!d_cands) n = h->last_count;
   const bool last = flags & PM_FINALIZE_LAST;
   if (n_out) *n_out = 0;
+  // out == NULL: the final hits stay in HBM (pm_final_hits_device) for the exchange step of a sharded scan
+  const bool keep = out == nullptr;
+  h->d_final = nullptr; h->n_final = 0;
+  if (keep && (flags & PM_FINALIZE_SORTED)) return fail(h, PM_E_INVALID, "pm_finalize_device: PM_FINALIZE_SORTED needs a host buffer");
   const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT;
   // edits on the seed family (A,C,G,T patterns of <= 32 characters): clusters and their DPs on the device
   const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && h->pats.size() < ((size_t)1 << 22);
@@ -1324,13 +1366,25 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const size_t nfin = (size_t)h->h_fcounts[0];
+    if (n_out) *n_out = nfin;
+    if (keep) { h->d_final = h->d_fout; h->n_final = nfin; return PM_OK; }
     if (nfin > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
     if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));
     if (flags & PM_FINALIZE_SORTED) sort_hits(out, nfin);
-    if (n_out) *n_out = nfin;
     return PM_OK;
   }
   if (!passthrough && !cluster) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this option set needs the host stage (pm_finalize)");
+  if (passthrough && keep) {
+    if (own.on) {                                                   // the records that end in the owned range, compacted on the device
+      { int rcw = ensure_sort_workspace(h, n, true); if (rcw) return rcw; }
+      HIP_TRY(h, owned_filter_device(src, n, own, h->d_fout, h->d_fcounts, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      h->d_final = h->d_fout; h->n_final = (size_t)h->h_fcounts[0];
+    } else { h->d_final = src; h->n_final = n; }
+    if (n_out) *n_out = h->n_final;
+    return PM_OK;
+  }
   if (passthrough) {
     if (n > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
     if (n) HIP_TRY(h, hipMemcpyAsync(out, src, n * sizeof(pm_hit), hipMemcpyDeviceToHost, h->stream));
@@ -1408,6 +1462,13 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     int rc = finalize_into(h, hostpart.data(), hostpart.size(), scanned_to, last, extra);
     if (rc) return rc;
     if (own.on) extra.erase(std::remove_if(extra.begin(), extra.end(), [&](const pm_hit &x) { return !(x.end > own.own_lo && x.end <= own.own_hi); }), extra.end());
+  }
+  if (keep) {                                                       // the few host-decided hits join the device's in HBM
+    if (nfin + extra.size() > h->ckeys_cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: device output buffer too small");
+    if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_fout + nfin, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
+    h->d_final = h->d_fout; h->n_final = nfin + extra.size();
+    if (n_out) *n_out = h->n_final;
+    return PM_OK;
   }
   if (nfin + extra.size() > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
   if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));

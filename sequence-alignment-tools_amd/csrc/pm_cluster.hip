@@ -397,6 +397,25 @@ hipError_t halves_rule_device(const pm_hit *d_in, size_t n, bool flags, int slac
   return hipGetLastError();
 }
 
+namespace {
+// pass-through engines on one shard of a position-sharded scan: keep the records that end in the
+// owned range (the same records, compacted; order unspecified)
+__global__ void pm_owned_filter(const pm_hit *in, size_t n, OwnedRange own, pm_hit *out, unsigned long long *out_count) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pm_hit h = in[i];
+  if (!hit_owned(own, h.end)) return;
+  out[wave_reserve_slot(out_count)] = h;
+}
+}  // namespace
+
+hipError_t owned_filter_device(const pm_hit *d_in, size_t n, const OwnedRange &own, pm_hit *d_out, unsigned long long *d_count, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess || n == 0) return e;
+  hipLaunchKernelGGL(pm_owned_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, n, own, d_out, d_count);
+  return hipGetLastError();
+}
+
 size_t cluster_temp_bytes(size_t n) {
   size_t bytes = 0;
   uint64_t *p = nullptr;

@@ -92,6 +92,9 @@ hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, si
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
 
 
+// records of d_in that end in the owned range, compacted into d_out (pass-through engines, sharded scans)
+hipError_t owned_filter_device(const pm_hit *d_in, size_t n, const OwnedRange &own, pm_hit *d_out, unsigned long long *d_count, hipStream_t st);
+
 constexpr uint32_t PM_SEED_HOLE = 0xffffffffu;   // pid of an unused slot in the half-seed record buffer
 constexpr int SEED_OUT_BLOCK = 64;               // slots a wave reserves per atomic (exact_halves -k seeds)
 

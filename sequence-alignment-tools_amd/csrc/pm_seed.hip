@@ -556,7 +556,8 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   extern __shared__ uint32_t lds[];
   uint32_t *bloom = lds;                                          // SEED_BLOOM_STRIDE dwords, at LDS address 0 (bloom_block)
   uint2 *queue_all = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_STRIDE);
-  if ((uint32_t)(uintptr_t)(lds_u32 *)lds != 0u) __builtin_trap();   // this kernel has no static LDS: the dynamic block starts at 0
+  // the filter must sit at LDS address 0 (bloom_block): these kernels have no static LDS, which
+  // seed_upload checks on the host (hipFuncGetAttributes) before anything is launched
 
   // blockIdx -> (combo, chunk): runs of `group` chunks share a combo, all combos of a superchunk
   // follow each other, so the stream bytes of a superchunk are re-read from MALL and the combo's
@@ -1282,8 +1283,14 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
                            reinterpret_cast<const void *>(pm_seed_scan<20, 0, false>), reinterpret_cast<const void *>(pm_seed_scan<0, 0, false>),
                            reinterpret_cast<const void *>(pm_seed_scan<0, 0, true>),
                            reinterpret_cast<const void *>(pm_seed_scan<20, 1, false, true>)};
-  for (const void *kf : kernels)
+  for (const void *kf : kernels) {
+    // bloom_block addresses the filter from LDS address 0: a kernel that acquired static LDS (which
+    // the dynamic block would follow) must fail here, at init, not compute with a shifted filter
+    hipFuncAttributes fa;
+    if ((e = hipFuncGetAttributes(&fa, kf)) != hipSuccess) return e;
+    if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
     if ((e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, SEED_LDS_BYTES)) != hipSuccess) return e;
+  }
   return hipStreamSynchronize(st);
 }
 

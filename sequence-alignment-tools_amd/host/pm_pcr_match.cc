@@ -30,17 +30,17 @@ using namespace pmgpu;
 namespace {
 
 struct Options {
-  bool pattern_file = false, sts_pattern_file = false, fasta_pattern_file = false;
-  std::string patterns, database, outfile;
-  int nmismatch = 0;
-  char eos_char = '\n';
-  std::string alignformat = ">%h\\n %>T %>s ... %l ... %<e %<T\\n %>A  %!>s    %!l    %!<e  %<A\\n %>Q %>r%!>s    %!l    %!<e%<r %<Q %a%R\\n";
-  bool verbose = false, memmap = true;
-  int dbind = 0, node = 0;
-  bool wc = false, tn = false, ucdict = false, allorient = false, rev_comp = false;
-  int maxdist = 2000, mindist = 0, deviation = -1, stlen = 0, edlen = 0, fplen = 0, tplen = 0, seedlen = 0;
-  bool indels = true, betweenlen = false;
-  unsigned long report_interval = 1000;
+  bool primers_from_file = false, primers_from_sts = false, primers_from_fasta = false;
+  std::string primer_arg, db_path, out_path;
+  int max_edits = 0;
+  char eos = '\n';
+  std::string hit_format = ">%h\\n %>T %>s ... %l ... %<e %<T\\n %>A  %!>s    %!l    %!<e  %<A\\n %>Q %>r%!>s    %!l    %!<e%<r %<Q %a%R\\n";
+  bool chatty = false, map_db = true;
+  int db_variant = 0, engine_choice = 0;
+  bool iupac = false, text_n_matches = false, to_upper = false, any_orientation = false, both_strands = false;
+  int amplicon_max = 2000, amplicon_min = 0, size_slack = -1, zone_start = 0, zone_end = 0, zone5 = 0, zone3 = 0, seed_len = 0;
+  bool with_indels = true, length_between = false;
+  unsigned long progress_every = 1000;
 };
 
 [[noreturn]] void usage(const char *msg = nullptr) {
@@ -61,41 +61,41 @@ Options parse(int argc, char **argv) {
   Options o;
   int c;
   while ((c = getopt(argc, argv, "p:i:o:P:S:F:E:R:k:K:s:e:5:3:x:hrvVubaA:BD:wWN:M:m:d:")) != -1) switch (c) {
-      case 'p': o.patterns = optarg; o.pattern_file = false; break;
-      case 'P': o.patterns = optarg; o.pattern_file = true; break;
-      case 'S': o.patterns = optarg; o.sts_pattern_file = true; break;
-      case 'F': o.patterns = optarg; o.fasta_pattern_file = true; break;
-      case 'i': o.database = optarg; break;
-      case 'o': o.outfile = optarg; break;
-      case 'k': o.nmismatch = atoi(optarg); o.indels = true; break;
-      case 'K': o.nmismatch = atoi(optarg); o.indels = false; break;
-      case '3': o.tplen = tilde(optarg); break;
-      case '5': o.fplen = tilde(optarg); break;
-      case 's': o.stlen = tilde(optarg); break;
-      case 'e': o.edlen = tilde(optarg); break;
-      case 'x': o.seedlen = atoi(optarg); break;
-      case 'R': o.report_interval = (unsigned long)atoi(optarg); break;
-      case 'A': o.alignformat = optarg; break;
-      case 'w': o.wc = true; o.tn = false; break;
-      case 'W': o.wc = true; o.tn = true; break;
-      case 'u': o.ucdict = true; break;
-      case 'D': o.dbind = atoi(optarg); break;
-      case 'N': o.node = atoi(optarg); break;
-      case 'M': o.maxdist = atoi(optarg); break;
-      case 'd': o.deviation = atoi(optarg); break;
-      case 'm': o.mindist = atoi(optarg); break;
-      case 'E': { int e0; if (!sscanf(optarg, "%i", &e0)) usage("Invalid end-of-sequence specification.\n"); o.eos_char = (char)e0; } break;
-      case 'v': case 'V': o.verbose = true; break;
-      case 'b': o.betweenlen = true; break;
-      case 'r': o.rev_comp = true; break;
-      case 'a': o.allorient = true; break;
-      case 'B': o.memmap = false; break;
+      case 'p': o.primer_arg = optarg; o.primers_from_file = false; break;
+      case 'P': o.primer_arg = optarg; o.primers_from_file = true; break;
+      case 'S': o.primer_arg = optarg; o.primers_from_sts = true; break;
+      case 'F': o.primer_arg = optarg; o.primers_from_fasta = true; break;
+      case 'i': o.db_path = optarg; break;
+      case 'o': o.out_path = optarg; break;
+      case 'k': o.max_edits = atoi(optarg); o.with_indels = true; break;
+      case 'K': o.max_edits = atoi(optarg); o.with_indels = false; break;
+      case '3': o.zone3 = tilde(optarg); break;
+      case '5': o.zone5 = tilde(optarg); break;
+      case 's': o.zone_start = tilde(optarg); break;
+      case 'e': o.zone_end = tilde(optarg); break;
+      case 'x': o.seed_len = atoi(optarg); break;
+      case 'R': o.progress_every = (unsigned long)atoi(optarg); break;
+      case 'A': o.hit_format = optarg; break;
+      case 'w': o.iupac = true; o.text_n_matches = false; break;
+      case 'W': o.iupac = true; o.text_n_matches = true; break;
+      case 'u': o.to_upper = true; break;
+      case 'D': o.db_variant = atoi(optarg); break;
+      case 'N': o.engine_choice = atoi(optarg); break;
+      case 'M': o.amplicon_max = atoi(optarg); break;
+      case 'd': o.size_slack = atoi(optarg); break;
+      case 'm': o.amplicon_min = atoi(optarg); break;
+      case 'E': { int e0; if (!sscanf(optarg, "%i", &e0)) usage("Invalid end-of-sequence specification.\n"); o.eos = (char)e0; } break;
+      case 'v': case 'V': o.chatty = true; break;
+      case 'b': o.length_between = true; break;
+      case 'r': o.both_strands = true; break;
+      case 'a': o.any_orientation = true; break;
+      case 'B': o.map_db = false; break;
       default: usage();
     }
-  if ((o.patterns.empty() || o.database.empty()) && !o.verbose) usage();
-  if (o.nmismatch < 0) usage("Number of mismatches (-k) must be at least 0");
-  if (o.dbind < 0 || o.dbind > 4) usage("Invalid integer for fasta database indexing (-D).");
-  if (o.dbind == 1 || o.dbind == 4) usage("Only indexed (-D 2) and normalized (-D 3) databases are supported; run pm_compress_seq first.");
+  if ((o.primer_arg.empty() || o.db_path.empty()) && !o.chatty) usage();
+  if (o.max_edits < 0) usage("Number of mismatches (-k) must be at least 0");
+  if (o.db_variant < 0 || o.db_variant > 4) usage("Invalid integer for fasta database indexing (-D).");
+  if (o.db_variant == 1 || o.db_variant == 4) usage("Only indexed (-D 2) and normalized (-D 3) databases are supported; run pm_compress_seq first.");
   return o;
 }
 
@@ -232,10 +232,10 @@ struct Hit { int64_t key; unsigned long id; unsigned char value; };
 
 int main(int argc, char **argv) {
   Options opt = parse(argc, argv);
-  Phases ph; ph.on = opt.verbose;
+  Phases ph; ph.on = opt.chatty;
   std::ofstream fout;
-  if (!opt.outfile.empty()) fout.open(opt.outfile.c_str(), std::ios::out | std::ios::app | std::ios::ate);
-  std::ostream &out = opt.outfile.empty() ? std::cout : fout;
+  if (!opt.out_path.empty()) fout.open(opt.out_path.c_str(), std::ios::out | std::ios::app | std::ios::ate);
+  std::ostream &out = opt.out_path.empty() ? std::cout : fout;
 
   // ---- primer pairs (pcr_match.cc:712-790) --------------------------------------------------
   std::vector<std::string> patterns, patdeflines;
@@ -243,14 +243,14 @@ int main(int argc, char **argv) {
   {
     std::ifstream file;
     std::istream *ifs = &std::cin;
-    if ((opt.pattern_file || opt.fasta_pattern_file || opt.sts_pattern_file) && opt.patterns != "-") {
-      file.open(opt.patterns.c_str());
+    if ((opt.primers_from_file || opt.primers_from_fasta || opt.primers_from_sts) && opt.primer_arg != "-") {
+      file.open(opt.primer_arg.c_str());
       ifs = &file;
     }
-    if (opt.pattern_file) {
+    if (opt.primers_from_file) {
       std::string p;
       while ((*ifs) >> p) patterns.push_back(p);
-    } else if (opt.sts_pattern_file) {
+    } else if (opt.primers_from_sts) {
       StsEntry s;
       for (;;) {
         read_sts_entry(*ifs, &s);
@@ -260,7 +260,7 @@ int main(int argc, char **argv) {
         patterns.push_back(s.forward_primer);
         patterns.push_back(s.reverse_primer);
       }
-    } else if (opt.fasta_pattern_file) {
+    } else if (opt.primers_from_fasta) {
       FastaEntry f;
       while (read_fasta_entry(*ifs, &f)) {
         if (f.sequence.empty()) break;
@@ -268,16 +268,16 @@ int main(int argc, char **argv) {
         patterns.push_back(f.sequence);
       }
     } else {
-      std::istringstream sis(opt.patterns);
+      std::istringstream sis(opt.primer_arg);
       std::string p;
       while (sis >> p) patterns.push_back(p);
     }
   }
   if (patterns.empty()) return 0;
   if (patterns.size() % 2 != 0) usage("Odd number of primers!");
-  if (opt.ucdict) for (std::string &p : patterns) uppercase(p);
-  if (opt.rev_comp || opt.sts_pattern_file) {
-    opt.rev_comp = true;
+  if (opt.to_upper) for (std::string &p : patterns) uppercase(p);
+  if (opt.both_strands || opt.primers_from_sts) {
+    opt.both_strands = true;
     for (size_t i = 1; i < patterns.size(); i += 2) patterns[i] = reverse_comp(patterns[i]);
   }
 
@@ -290,40 +290,40 @@ int main(int argc, char **argv) {
   for (unsigned long i = 1; i <= n; ++i) {              // pcr_match.cc:806-906
     const std::string &pat = patterns[i - 1];
     const int L = (int)pat.length();
-    int fplen = opt.fplen, tplen = opt.tplen;
-    if (i % 2 == 0) { fplen = opt.tplen; tplen = opt.fplen; }
+    int fplen = opt.zone5, tplen = opt.zone3;
+    if (i % 2 == 0) { fplen = opt.zone3; tplen = opt.zone5; }
     patarray[i] = pat; patlen[i] = L;
-    if (opt.sts_pattern_file && i % 2 == 1) stsarray[(i + 1) / 2] = sts[(i - 1) / 2];
-    if (opt.fasta_pattern_file) patdefarray[i] = patdeflines[i - 1];
+    if (opt.primers_from_sts && i % 2 == 1) stsarray[(i + 1) / 2] = sts[(i - 1) / 2];
+    if (opt.primers_from_fasta) patdefarray[i] = patdeflines[i - 1];
     int &f1 = patconst[i].first, &s1 = patconst[i].second;
-    f1 = opt.stlen > 0 ? opt.stlen : 0;
+    f1 = opt.zone_start > 0 ? opt.zone_start : 0;
     if (fplen > f1) f1 = fplen;
-    if (opt.edlen < 0 && L + opt.edlen > f1) f1 = L + opt.edlen;
+    if (opt.zone_end < 0 && L + opt.zone_end > f1) f1 = L + opt.zone_end;
     if (tplen < 0 && L + tplen > f1) f1 = L + tplen;
-    s1 = opt.edlen > 0 ? opt.edlen : 0;
+    s1 = opt.zone_end > 0 ? opt.zone_end : 0;
     if (tplen > s1) s1 = tplen;
-    if (opt.stlen < 0 && L + opt.stlen > s1) s1 = L + opt.stlen;
+    if (opt.zone_start < 0 && L + opt.zone_start > s1) s1 = L + opt.zone_start;
     if (fplen < 0 && L + fplen > s1) s1 = L + fplen;
     patarray[i + n] = reverse_comp(pat); patlen[i + n] = L;
     int &f2 = patconst[i + n].first, &s2 = patconst[i + n].second;
-    f2 = opt.stlen > 0 ? opt.stlen : 0;
+    f2 = opt.zone_start > 0 ? opt.zone_start : 0;
     if (tplen > f2) f2 = tplen;
-    if (opt.edlen < 0 && L + opt.edlen > f2) f2 = L + opt.edlen;
+    if (opt.zone_end < 0 && L + opt.zone_end > f2) f2 = L + opt.zone_end;
     if (fplen < 0 && L + fplen > f2) f2 = L + fplen;
-    s2 = opt.edlen > 0 ? opt.edlen : 0;
+    s2 = opt.zone_end > 0 ? opt.zone_end : 0;
     if (fplen > s2) s2 = fplen;
-    if (opt.stlen < 0 && L + opt.stlen > s2) s2 = L + opt.stlen;
+    if (opt.zone_start < 0 && L + opt.zone_start > s2) s2 = L + opt.zone_start;
     if (tplen < 0 && L + tplen > s2) s2 = L + tplen;
   }
 
   // ---- database and engine (pcr_match.cc:911-931) -------------------------------------------
   ph.mark("Read primer pairs");
-  SeqDb db(opt.database, opt.dbind, /*load_headers=*/true, /*check=*/true, /*upper_case=*/false, opt.eos_char, opt.memmap);
+  SeqDb db(opt.db_path, opt.db_variant, /*load_headers=*/true, /*check=*/true, /*upper_case=*/false, opt.eos, opt.map_db);
   ph.mark("Loaded sequence database");
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
-  if (opt.node == 16) kernel = PM_KERNEL_BITPAR;
-  else if (opt.node != 17 && opt.node != 0) semantics = opt.node;
-  GpuPatternMatch pm(kernel, (unsigned)opt.nmismatch, opt.eos_char, opt.wc, opt.tn, opt.indels, false, semantics);
+  if (opt.engine_choice == 16) kernel = PM_KERNEL_BITPAR;
+  else if (opt.engine_choice != 17 && opt.engine_choice != 0) semantics = opt.engine_choice;
+  GpuPatternMatch pm(kernel, (unsigned)opt.max_edits, opt.eos, opt.iupac, opt.text_n_matches, opt.with_indels, false, semantics);
   size_t maxlen = 0;
   for (unsigned long i = 1; i <= N1; ++i) {
     pm.add_pattern(patarray[i], i, patconst[i].first, patconst[i].second);
@@ -336,14 +336,14 @@ int main(int argc, char **argv) {
   unsigned long nhits = 0, npairs = 0;
 
   // ---- scan + pairing (pcr_match.cc:937-1259) ------------------------------------------------
-  const size_t stride = maxlen + (size_t)opt.nmismatch + 2;
-  const int slack = opt.indels ? opt.nmismatch : 1;
+  const size_t stride = maxlen + (size_t)opt.max_edits + 2;
+  const int slack = opt.with_indels ? opt.max_edits : 1;
   pattern_hit_vector l;
   StsEntry null_sts;
   for (;;) {
     const auto ts0 = std::chrono::steady_clock::now();
     const size_t before = l.size();
-    const bool more = pm.find_patterns(ff, l, opt.report_interval);
+    const bool more = pm.find_patterns(ff, l, opt.progress_every);
     const auto ts1 = std::chrono::steady_clock::now();
     t_scan += std::chrono::duration<double>(ts1 - ts0).count();
     if (!more && l.empty()) break;
@@ -364,7 +364,7 @@ int main(int argc, char **argv) {
       unsigned long pid1 = 0, pid2 = 0;
       if (pid <= n && pid % 2 == 1) pid1 = pid + 1;
       else if (pid > n && (pid - n) % 2 == 0) pid1 = pid - 1;
-      if (opt.allorient) {
+      if (opt.any_orientation) {
         if (pid <= n) {
           if (pid % 2 == 1) pid2 = pid + n + 1;
           else { pid1 = pid - 1; pid2 = pid + n - 1; }
@@ -374,16 +374,16 @@ int main(int argc, char **argv) {
         }
       }
       const unsigned long pair = (pid - (pid > n ? n : 0) + 1) / 2;
-      int64_t stretch_max = opt.maxdist, stretch_min = opt.mindist;
-      if (opt.betweenlen) {
+      int64_t stretch_max = opt.amplicon_max, stretch_min = opt.amplicon_min;
+      if (opt.length_between) {
         int64_t plen = 0;
         if (pid1 != 0) plen = patlen[pid1];
         if (pid2 != 0 && patlen[pid2] > plen) plen = patlen[pid2];
         stretch_max += plen + patlen[pid];
       }
-      if (opt.sts_pattern_file && opt.deviation >= 0) {  // unsigned comparisons as in the reference (:1040-1047)
-        const uint64_t ub = (uint64_t)stsarray[pair].sizeub + (uint64_t)(int64_t)opt.deviation;
-        const uint64_t lb = (uint64_t)stsarray[pair].sizelb - (uint64_t)(int64_t)opt.deviation;
+      if (opt.primers_from_sts && opt.size_slack >= 0) {  // unsigned comparisons as in the reference (:1040-1047)
+        const uint64_t ub = (uint64_t)stsarray[pair].sizeub + (uint64_t)(int64_t)opt.size_slack;
+        const uint64_t lb = (uint64_t)stsarray[pair].sizelb - (uint64_t)(int64_t)opt.size_slack;
         if ((uint64_t)stretch_max > ub) stretch_max = (int64_t)ub;
         if ((uint64_t)stretch_min < lb) stretch_min = (int64_t)lb;
       }
@@ -423,7 +423,7 @@ int main(int argc, char **argv) {
     for (const auto &pr : todo) {
       const size_t ja = pr.first, jb = pr.second;
       const pm_alignment &pa = al[slot[ja]], &pa1 = al[slot[jb]];
-      if (pa.editdist < 0 || pa.editdist > opt.nmismatch || pa1.editdist < 0 || pa1.editdist > opt.nmismatch) continue;
+      if (pa.editdist < 0 || pa.editdist > opt.max_edits || pa1.editdist < 0 || pa1.editdist > opt.max_edits) continue;
       const unsigned long pid = l[ja].id, pid1 = l[jb].id;
       const long long len = pa.end - pa.start + 1, len1 = pa1.end - pa1.start + 1;
       const long long spe = db.get_seq_pos(pa.end), spe1 = db.get_seq_pos(pa1.end);
@@ -432,15 +432,15 @@ int main(int argc, char **argv) {
       bool rc = pid > n, rc1 = pid1 > n;
       const unsigned long ind = pid - (rc ? n : 0), ind1 = pid1 - (rc1 ? n : 0);
       const unsigned long pind = ind < ind1 ? ind / 2 + 1 : ind1 / 2 + 1;
-      const StsEntry &stsref = opt.sts_pattern_file ? stsarray[pind] : null_sts;
-      if (opt.rev_comp) {
+      const StsEntry &stsref = opt.primers_from_sts ? stsarray[pind] : null_sts;
+      if (opt.both_strands) {
         if (ind % 2 == 0) rc = !rc;
         else if (ind1 % 2 == 0) rc1 = !rc1;
       }
-      const long amplicon_len = !opt.betweenlen ? (long)(pe1 - ps) : (long)(ps1 - pe);
-      if (!(db.is_subseq(ps, pe1) && amplicon_len <= opt.maxdist && amplicon_len >= opt.mindist &&
-            (!opt.sts_pattern_file || opt.deviation < 0 ||
-             (((unsigned long)(amplicon_len + opt.deviation) >= stsref.sizelb) && (amplicon_len <= (long)((int)stsref.sizeub) + opt.deviation)))))
+      const long amplicon_len = !opt.length_between ? (long)(pe1 - ps) : (long)(ps1 - pe);
+      if (!(db.is_subseq(ps, pe1) && amplicon_len <= opt.amplicon_max && amplicon_len >= opt.amplicon_min &&
+            (!opt.primers_from_sts || opt.size_slack < 0 ||
+             (((unsigned long)(amplicon_len + opt.size_slack) >= stsref.sizelb) && (amplicon_len <= (long)((int)stsref.sizeub) + opt.size_slack)))))
         continue;
       const HeaderData &h = db.get_header_data(pa.end);
       PairFields x;
@@ -455,14 +455,14 @@ int main(int argc, char **argv) {
       const std::string ops(opsbuf.data() + slot[ja] * stride), mt(textbuf.data() + slot[ja] * stride);
       const std::string ops1(opsbuf.data() + slot[jb] * stride), mt1(textbuf.data() + slot[jb] * stride);
       x.a = End{sps, spe, rc ? spe : sps, rc ? sps : spe, ps, pe, (unsigned)pa.editdist, patarray[ind],
-                opt.fasta_pattern_file ? patdefarray[ind] : std::string(), patarray[pid], with_gaps(patarray[pid], ops, '^'),
+                opt.primers_from_fasta ? patdefarray[ind] : std::string(), patarray[pid], with_gaps(patarray[pid], ops, '^'),
                 rc ? "R" : "F", rc ? " REVCOMP" : "", mt, with_gaps(mt, ops, 'v'), ops};
       x.b = End{sps1, spe1, rc1 ? spe1 : sps1, rc1 ? sps1 : spe1, ps1, pe1, (unsigned)pa1.editdist, patarray[ind1],
-                opt.fasta_pattern_file ? patdefarray[ind1] : std::string(), patarray[pid1], with_gaps(patarray[pid1], ops1, '^'),
+                opt.primers_from_fasta ? patdefarray[ind1] : std::string(), patarray[pid1], with_gaps(patarray[pid1], ops1, '^'),
                 rc1 ? "R" : "F", rc1 ? " REVCOMP" : "", mt1, with_gaps(mt1, ops1, 'v'), ops1};
       x.i = pind; x.sts = &stsref; x.ppo = ind < ind1;
       x.h = h.header; x.H = h.short_header; x.f = h.index;
-      alignformat(out, opt.alignformat, x);
+      alignformat(out, opt.hit_format, x);
       ++npairs;
     }
 
@@ -474,7 +474,7 @@ int main(int argc, char **argv) {
     ff.pos(oldcharspos);
     t_pair += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count();
   }
-  if (opt.verbose) fprintf(stderr, "scan (find_patterns) %.3f s, pairing + re-align + report %.3f s, %lu primer hits, %lu amplicons\n", t_scan, t_pair, nhits, npairs);
+  if (opt.chatty) fprintf(stderr, "scan (find_patterns) %.3f s, pairing + re-align + report %.3f s, %lu primer hits, %lu amplicons\n", t_scan, t_pair, nhits, npairs);
   ph.mark("Scanned sequence database");
   out.flush();
   return 0;

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
 #include "seq_io.h"
 
 using namespace pmgpu;
@@ -29,21 +30,21 @@ using namespace pmgpu;
 namespace {
 
 struct Options {
-  bool rev_comp = false, pattern_file = false, fasta_pattern_file = false, sts_pattern_file = false;
-  std::string patterns, database;
-  bool ucdict = false;
-  int tplen = 0, fplen = 0, stlen = 0, edlen = 0, seedlen = 0;
-  char eos_char = '\n';
-  int nmismatch = 0, maxcount = 0;
-  std::string alignformat = ">%h\\n %T %s %e %d\\n %A\\n %Q %i%R\\n";
-  bool alignments = true;
-  std::string countformat = "%i %r %q %c%+ ( %C )\\n";
-  bool counts = false;
-  std::string outfile;
-  unsigned long report_interval = 1000;
-  bool verbose = false, memmap = true;
-  int node = 0, dbind = 0;
-  bool dbindex = true, wc = false, tn = false, indels = true, aggregate = false, dna_mutations = false, translate = false;
+  bool both_strands = false, primers_from_file = false, primers_from_fasta = false, primers_from_sts = false;
+  std::string primer_arg, db_path;
+  bool to_upper = false;
+  int zone3 = 0, zone5 = 0, zone_start = 0, zone_end = 0, seed_len = 0;
+  char eos = '\n';
+  int max_edits = 0, count_cap = 0;
+  std::string hit_format = ">%h\\n %T %s %e %d\\n %A\\n %Q %i%R\\n";
+  bool print_hits = true;
+  std::string tally_format = "%i %r %q %c%+ ( %C )\\n";
+  bool print_tallies = false;
+  std::string out_path;
+  unsigned long progress_every = 1000;
+  bool chatty = false, map_db = true;
+  int engine_choice = 0, db_variant = 0;
+  bool use_db_index = true, iupac = false, text_n_matches = false, with_indels = true, merge_tallies = false, dna_scoring = false, translated = false;
 };
 
 [[noreturn]] void usage(const char *msg = nullptr) {
@@ -69,49 +70,49 @@ Options parse(int argc, char **argv) {
   Options o;
   int c;
   while ((c = getopt(argc, argv, "p:i:o:P:F:S:M:k:K:s:e:3:5:x:E:hrucavA:C:R:BN:D:IwWT")) != -1) switch (c) {
-      case 'p': o.patterns = optarg; o.pattern_file = false; break;
-      case 'P': o.patterns = optarg; o.pattern_file = true; break;
-      case 'F': o.patterns = optarg; o.fasta_pattern_file = true; break;
-      case 'S': o.patterns = optarg; o.sts_pattern_file = true; o.rev_comp = true; break;
-      case 'i': o.database = optarg; break;
-      case 'o': o.outfile = optarg; break;
-      case '3': o.tplen = tilde(optarg); break;
-      case '5': o.fplen = tilde(optarg); break;
-      case 's': o.stlen = tilde(optarg); break;
-      case 'e': o.edlen = tilde(optarg); break;
+      case 'p': o.primer_arg = optarg; o.primers_from_file = false; break;
+      case 'P': o.primer_arg = optarg; o.primers_from_file = true; break;
+      case 'F': o.primer_arg = optarg; o.primers_from_fasta = true; break;
+      case 'S': o.primer_arg = optarg; o.primers_from_sts = true; o.both_strands = true; break;
+      case 'i': o.db_path = optarg; break;
+      case 'o': o.out_path = optarg; break;
+      case '3': o.zone3 = tilde(optarg); break;
+      case '5': o.zone5 = tilde(optarg); break;
+      case 's': o.zone_start = tilde(optarg); break;
+      case 'e': o.zone_end = tilde(optarg); break;
       case 'k':
       case 'K':
-        if (optarg[0] == '.') { o.nmismatch = atoi(optarg + 1); o.dna_mutations = true; } else o.nmismatch = atoi(optarg);
-        o.indels = c == 'k';
+        if (optarg[0] == '.') { o.max_edits = atoi(optarg + 1); o.dna_scoring = true; } else o.max_edits = atoi(optarg);
+        o.with_indels = c == 'k';
         break;
-      case 'r': o.rev_comp = true; break;
-      case 'c': o.counts = true; o.alignments = false; break;
-      case 'M': o.maxcount = atoi(optarg); break;
-      case 'x': o.seedlen = atoi(optarg); break;
-      case 'A': if (strlen(optarg) > 0) o.alignformat = optarg; o.alignments = true; break;
-      case 'C': if (strlen(optarg) > 0) o.countformat = optarg; o.counts = true; break;
-      case 'u': o.ucdict = true; break;
-      case 'a': o.aggregate = true; break;
-      case 'T': o.translate = true; break;
-      case 'w': o.wc = true; o.tn = false; break;
-      case 'W': o.wc = true; o.tn = true; break;
-      case 'R': o.report_interval = (unsigned long)atoi(optarg); break;
-      case 'N': o.node = atoi(optarg); break;
-      case 'D': o.dbind = atoi(optarg); break;
-      case 'E': { int ec; if (!sscanf(optarg, "%i", &ec)) usage("Invalid end-of-sequence specification.\n"); o.eos_char = (char)ec; } break;
-      case 'v': o.verbose = true; break;
-      case 'I': o.dbindex = false; break;
-      case 'B': o.memmap = false; break;
+      case 'r': o.both_strands = true; break;
+      case 'c': o.print_tallies = true; o.print_hits = false; break;
+      case 'M': o.count_cap = atoi(optarg); break;
+      case 'x': o.seed_len = atoi(optarg); break;
+      case 'A': if (strlen(optarg) > 0) o.hit_format = optarg; o.print_hits = true; break;
+      case 'C': if (strlen(optarg) > 0) o.tally_format = optarg; o.print_tallies = true; break;
+      case 'u': o.to_upper = true; break;
+      case 'a': o.merge_tallies = true; break;
+      case 'T': o.translated = true; break;
+      case 'w': o.iupac = true; o.text_n_matches = false; break;
+      case 'W': o.iupac = true; o.text_n_matches = true; break;
+      case 'R': o.progress_every = (unsigned long)atoi(optarg); break;
+      case 'N': o.engine_choice = atoi(optarg); break;
+      case 'D': o.db_variant = atoi(optarg); break;
+      case 'E': { int ec; if (!sscanf(optarg, "%i", &ec)) usage("Invalid end-of-sequence specification.\n"); o.eos = (char)ec; } break;
+      case 'v': o.chatty = true; break;
+      case 'I': o.use_db_index = false; break;
+      case 'B': o.map_db = false; break;
       default: usage();
     }
-  if ((o.patterns.empty() || o.database.empty()) && !o.verbose) usage("No primers and/or no sequence database supplied.");
-  if (o.nmismatch < 0) usage("Number of mismatches (-k) must be >= 0.");
-  if (o.maxcount > 0 && !o.counts) usage("Can''t use maxcount (-M) without counts (-c or -C).");
-  if (o.aggregate && !o.counts) usage("Can''t use aggregate (-a) without counts (-c or -C).");
-  if (o.dbind < 0 || o.dbind > 4) usage("Invalid integer for fasta database indexing (-D).");
-  if (o.dna_mutations) usage("DNA mutation scoring (-k .N) is not available on the GPU engine.");
-  if (o.translate) usage("Translation (-T) is not available on the GPU engine.");
-  if (o.dbind == 1 || o.dbind == 4) usage("Only indexed (-D 2) and normalized (-D 3) databases are supported; run pm_compress_seq first.");
+  if ((o.primer_arg.empty() || o.db_path.empty()) && !o.chatty) usage("No primers and/or no sequence database supplied.");
+  if (o.max_edits < 0) usage("Number of mismatches (-k) must be >= 0.");
+  if (o.count_cap > 0 && !o.print_tallies) usage("Can''t use maxcount (-M) without counts (-c or -C).");
+  if (o.merge_tallies && !o.print_tallies) usage("Can''t use aggregate (-a) without counts (-c or -C).");
+  if (o.db_variant < 0 || o.db_variant > 4) usage("Invalid integer for fasta database indexing (-D).");
+  if (o.dna_scoring) usage("DNA mutation scoring (-k .N) is not available on the GPU engine.");
+  if (o.translated) usage("Translation (-T) is not available on the GPU engine.");
+  if (o.db_variant == 1 || o.db_variant == 4) usage("Only indexed (-D 2) and normalized (-D 3) databases are supported; run pm_compress_seq first.");
   return o;
 }
 
@@ -141,6 +142,28 @@ struct AlignFields {                                   // the arguments of align
   unsigned long f;
   const StsEntry *sts;
 };
+
+// "%=": text / alignment / pattern rows cut into slices of 50 columns.  After each text slice come
+// the offsets of its first and one-past-last text character inside the matched text (a 'v' column
+// is a gap in the text and consumes none) and the slice's number of edit columns (every column
+// that is neither '|' nor '+'); slices are separated by an empty line.
+void wrapped_layout(std::ostream &os, const AlignFields &a) {
+  constexpr size_t ROW = 50;
+  const size_t total = a.T.size();
+  size_t text_at = 0;
+  for (size_t from = 0; from < total; from += ROW) {
+    const size_t cols = std::min(ROW, total - from);
+    const std::string ops = a.A.substr(from, cols);
+    const size_t gaps = (size_t)std::count(ops.begin(), ops.end(), 'v');
+    const size_t same = (size_t)std::count_if(ops.begin(), ops.end(), [](char c) { return c == '|' || c == '+'; });
+    const size_t text_to = text_at + cols - gaps;
+    os << ' ' << a.T.substr(from, ROW) << ' ' << text_at << ' ' << text_to << ' ' << cols - same << '\n'
+       << ' ' << ops << '\n'
+       << ' ' << a.Q.substr(from, ROW) << ' ' << a.i << a.R << '\n';
+    if (from + ROW < total) os << std::endl;
+    text_at = text_to;
+  }
+}
 
 void alignformat(std::ostream &os, const std::string &fmt, const AlignFields &a) {
   unsigned ins = 0, del = 0, sub = 0, wcm = 0, mat = 0;
@@ -192,24 +215,7 @@ void alignformat(std::ostream &os, const std::string &fmt, const AlignFields &a)
         case 'v': tally(); os << ins; break;
         case '*': tally(); os << sub; break;
         case '+': tally(); os << wcm; break;
-        case '=': {                                   // the default layout wrapped at 50 columns (:593-628)
-          const unsigned len0 = (unsigned)a.T.length(), width0 = 50;
-          unsigned textchars_start = 0;
-          for (unsigned i0 = 0; i0 < len0; i0 += width0) {
-            unsigned nchars = width0;
-            if (i0 + nchars > len0) nchars = len0 - i0;
-            unsigned textchars_end = textchars_start + nchars, editcount0 = nchars;
-            for (unsigned j0 = 0; j0 < nchars; ++j0) {
-              if (a.A[i0 + j0] == '|' || a.A[i0 + j0] == '+') --editcount0;
-              if (a.A[i0 + j0] == 'v') --textchars_end;
-            }
-            os << " " << a.T.substr(i0, width0) << " " << textchars_start << " " << textchars_end << " " << editcount0 << "\n"
-               << " " << a.A.substr(i0, width0) << "\n"
-               << " " << a.Q.substr(i0, width0) << " " << a.i << a.R << "\n";
-            if (len0 - i0 > width0) os << std::endl;
-            textchars_start = textchars_end;
-          }
-        } break;
+        case '=': wrapped_layout(os, a); break;        // the default layout, 50 alignment columns per row (:593-628)
         default: os << fmt[pos];
       }
     } else if (fmt[pos] == '\\') {
@@ -269,10 +275,10 @@ std::string with_gaps(const std::string &src, const std::string &ops, char gap_o
 
 int main(int argc, char **argv) {
   Options opt = parse(argc, argv);
-  Phases ph; ph.on = opt.verbose;
+  Phases ph; ph.on = opt.chatty;
   std::ofstream fout;
-  if (!opt.outfile.empty()) fout.open(opt.outfile.c_str(), std::ios::out | std::ios::app | std::ios::ate);
-  std::ostream &out = opt.outfile.empty() ? std::cout : fout;
+  if (!opt.out_path.empty()) fout.open(opt.out_path.c_str(), std::ios::out | std::ios::app | std::ios::ate);
+  std::ostream &out = opt.out_path.empty() ? std::cout : fout;
 
   // ---- primers (primer_match.cc:866-934) ----------------------------------------------------
   std::vector<std::string> patterns, patdeflines;
@@ -280,21 +286,21 @@ int main(int argc, char **argv) {
   {
     std::ifstream file;
     std::istream *ifs = &std::cin;
-    if ((opt.pattern_file || opt.fasta_pattern_file || opt.sts_pattern_file) && opt.patterns != "-") {
-      file.open(opt.patterns.c_str());
+    if ((opt.primers_from_file || opt.primers_from_fasta || opt.primers_from_sts) && opt.primer_arg != "-") {
+      file.open(opt.primer_arg.c_str());
       ifs = &file;
     }
-    if (opt.pattern_file) {
+    if (opt.primers_from_file) {
       std::string p;
       while ((*ifs) >> p) patterns.push_back(p);
-    } else if (opt.fasta_pattern_file) {
+    } else if (opt.primers_from_fasta) {
       FastaEntry f;
       while (read_fasta_entry(*ifs, &f)) {
         if (f.sequence.empty()) break;
         patterns.push_back(f.sequence);
         patdeflines.push_back(f.defline);
       }
-    } else if (opt.sts_pattern_file) {
+    } else if (opt.primers_from_sts) {
       StsEntry s;
       for (;;) {
         read_sts_entry(*ifs, &s);
@@ -305,62 +311,62 @@ int main(int argc, char **argv) {
         sts.push_back(s);
       }
     } else {
-      std::istringstream sis(opt.patterns);
+      std::istringstream sis(opt.primer_arg);
       std::string p;
       while (sis >> p) patterns.push_back(p);
     }
   }
   if (patterns.empty()) return 0;
   ph.mark("Read primers");
-  if (opt.ucdict) for (std::string &p : patterns) uppercase(p);
+  if (opt.to_upper) for (std::string &p : patterns) uppercase(p);
 
   const unsigned long n = patterns.size();
-  const unsigned long N1 = (opt.rev_comp ? 2 : 1) * n;
+  const unsigned long N1 = (opt.both_strands ? 2 : 1) * n;
   std::vector<std::string> patarray(N1 + 1);
   std::vector<std::pair<int, int>> patconst(N1 + 1);
-  std::vector<std::string> patdefarray(opt.fasta_pattern_file ? n + 1 : 0);
-  std::vector<StsEntry> stsarray(opt.sts_pattern_file ? n / 2 + 1 : 0);
-  const unsigned K1 = (unsigned)opt.nmismatch + 1;
-  std::vector<unsigned long> patcount(opt.counts ? N1 * K1 : 0, 0);
-  std::vector<bool> maxpatcount(opt.counts && opt.maxcount > 0 ? N1 + 1 : 0, false);
+  std::vector<std::string> patdefarray(opt.primers_from_fasta ? n + 1 : 0);
+  std::vector<StsEntry> stsarray(opt.primers_from_sts ? n / 2 + 1 : 0);
+  const unsigned K1 = (unsigned)opt.max_edits + 1;
+  std::vector<unsigned long> patcount(opt.print_tallies ? N1 * K1 : 0, 0);
+  std::vector<bool> maxpatcount(opt.print_tallies && opt.count_cap > 0 ? N1 + 1 : 0, false);
   auto cidx = [&](unsigned long i, unsigned k) { return (i - 1) * K1 + k; };
   for (unsigned long i = 1; i <= n; ++i) {              // primer_match.cc:966-1076
     const std::string &pat = patterns[i - 1];
     const int L = (int)pat.length();
     patarray[i] = pat;
-    if (opt.fasta_pattern_file) patdefarray[i] = patdeflines[i - 1];
-    if (opt.sts_pattern_file && i % 2 == 1) stsarray[(i + 1) / 2] = sts[(i - 1) / 2];
+    if (opt.primers_from_fasta) patdefarray[i] = patdeflines[i - 1];
+    if (opt.primers_from_sts && i % 2 == 1) stsarray[(i + 1) / 2] = sts[(i - 1) / 2];
     int &f1 = patconst[i].first, &s1 = patconst[i].second;
-    f1 = opt.stlen > 0 ? opt.stlen : 0;
-    if (opt.fplen > f1) f1 = opt.fplen;
-    if (opt.edlen < 0 && L + opt.edlen > f1) f1 = L + opt.edlen;
-    if (opt.tplen < 0 && L + opt.tplen > f1) f1 = L + opt.tplen;
-    s1 = opt.edlen > 0 ? opt.edlen : 0;
-    if (opt.tplen > s1) s1 = opt.tplen;
-    if (opt.stlen < 0 && L + opt.stlen > s1) s1 = L + opt.stlen;
-    if (opt.fplen < 0 && L + opt.fplen > s1) s1 = L + opt.fplen;
-    if (opt.rev_comp) {
+    f1 = opt.zone_start > 0 ? opt.zone_start : 0;
+    if (opt.zone5 > f1) f1 = opt.zone5;
+    if (opt.zone_end < 0 && L + opt.zone_end > f1) f1 = L + opt.zone_end;
+    if (opt.zone3 < 0 && L + opt.zone3 > f1) f1 = L + opt.zone3;
+    s1 = opt.zone_end > 0 ? opt.zone_end : 0;
+    if (opt.zone3 > s1) s1 = opt.zone3;
+    if (opt.zone_start < 0 && L + opt.zone_start > s1) s1 = L + opt.zone_start;
+    if (opt.zone5 < 0 && L + opt.zone5 > s1) s1 = L + opt.zone5;
+    if (opt.both_strands) {
       patarray[i + n] = reverse_comp(pat);
       int &f2 = patconst[i + n].first, &s2 = patconst[i + n].second;
-      f2 = opt.stlen > 0 ? opt.stlen : 0;
-      if (opt.tplen > f2) f2 = opt.tplen;
-      if (opt.edlen < 0 && L + opt.edlen > f2) f2 = L + opt.edlen;
-      if (opt.fplen < 0 && L + opt.fplen > f2) f2 = L + opt.fplen;
-      s2 = opt.edlen > 0 ? opt.edlen : 0;
-      if (opt.fplen > s2) s2 = opt.fplen;
-      if (opt.stlen < 0 && L + opt.stlen > s2) s2 = L + opt.stlen;
-      if (opt.tplen < 0 && L + opt.tplen > s2) s2 = L + opt.tplen;
+      f2 = opt.zone_start > 0 ? opt.zone_start : 0;
+      if (opt.zone3 > f2) f2 = opt.zone3;
+      if (opt.zone_end < 0 && L + opt.zone_end > f2) f2 = L + opt.zone_end;
+      if (opt.zone5 < 0 && L + opt.zone5 > f2) f2 = L + opt.zone5;
+      s2 = opt.zone_end > 0 ? opt.zone_end : 0;
+      if (opt.zone5 > s2) s2 = opt.zone5;
+      if (opt.zone_start < 0 && L + opt.zone_start > s2) s2 = L + opt.zone_start;
+      if (opt.zone3 < 0 && L + opt.zone3 > s2) s2 = L + opt.zone3;
     }
   }
 
   // ---- database and engine (primer_match.cc:1086-1112) --------------------------------------
-  SeqDb db(opt.database, opt.dbind, opt.alignments && opt.dbindex, opt.dbindex, opt.ucdict, opt.eos_char, opt.memmap);
+  SeqDb db(opt.db_path, opt.db_variant, opt.print_hits && opt.use_db_index, opt.use_db_index, opt.to_upper, opt.eos, opt.map_db);
   ph.mark("Loaded sequence database");
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
-  if (opt.node == 16) kernel = PM_KERNEL_BITPAR;
-  else if (opt.node == 17 || opt.node == 0) kernel = PM_KERNEL_AUTO;
-  else semantics = opt.node;                            // reproduce that reference engine's hit set
-  GpuPatternMatch kt(kernel, (unsigned)opt.nmismatch, opt.eos_char, opt.wc, opt.tn, opt.indels, false, semantics);
+  if (opt.engine_choice == 16) kernel = PM_KERNEL_BITPAR;
+  else if (opt.engine_choice == 17 || opt.engine_choice == 0) kernel = PM_KERNEL_AUTO;
+  else semantics = opt.engine_choice;                            // reproduce that reference engine's hit set
+  GpuPatternMatch kt(kernel, (unsigned)opt.max_edits, opt.eos, opt.iupac, opt.text_n_matches, opt.with_indels, false, semantics);
   size_t maxlen = 0;
   for (unsigned long i = 1; i <= N1; ++i) {
     kt.add_pattern(patarray[i], i, patconst[i].first, patconst[i].second);
@@ -373,7 +379,7 @@ int main(int argc, char **argv) {
   unsigned long nhits = 0;
 
   // ---- scan loop (primer_match.cc:1114-1268) ------------------------------------------------
-  const size_t stride = maxlen + (size_t)opt.nmismatch + 2;
+  const size_t stride = maxlen + (size_t)opt.max_edits + 2;
   pattern_hit_vector l;
   std::vector<pm_hit> hv;
   std::vector<pm_alignment> al;
@@ -381,33 +387,33 @@ int main(int argc, char **argv) {
   StsEntry null_sts;
   for (;;) {
     const auto ts0 = std::chrono::steady_clock::now();
-    const bool more = kt.find_patterns(ff, l, opt.report_interval);
+    const bool more = kt.find_patterns(ff, l, opt.progress_every);
     const auto ts1 = std::chrono::steady_clock::now();
     t_scan += std::chrono::duration<double>(ts1 - ts0).count();
     if (!more && l.empty()) break;
     nhits += l.size();
     const int64_t oldcharspos = ff.pos();
     hv.resize(l.size()); al.resize(l.size());
-    if (opt.alignments) { opsbuf.assign(l.size() * stride, 0); textbuf.assign(l.size() * stride, 0); }
+    if (opt.print_hits) { opsbuf.assign(l.size() * stride, 0); textbuf.assign(l.size() * stride, 0); }
     for (size_t j = 0; j < l.size(); ++j) { hv[j].end = l[j].key; hv[j].pid = (uint32_t)l[j].id; hv[j].k = l[j].value; hv[j].aux[0] = hv[j].aux[1] = hv[j].aux[2] = 0; }
     // counts only (-c): distances are enough, no alignment strings
-    if (!l.empty() && (opt.alignments ? pm_align_hits_text(kt.handle(), hv.data(), hv.size(), al.data(), opsbuf.data(), textbuf.data(), stride)
+    if (!l.empty() && (opt.print_hits ? pm_align_hits_text(kt.handle(), hv.data(), hv.size(), al.data(), opsbuf.data(), textbuf.data(), stride)
                                       : pm_align_hits(kt.handle(), hv.data(), hv.size(), al.data())) != PM_OK) {
       fprintf(stderr, "Fatal error: alignment: %s\n", pm_last_error(kt.handle()));
       return 1;
     }
     for (size_t j = 0; j < l.size(); ++j) {
       const unsigned long pid = l[j].id;
-      if (!pid || (opt.maxcount > 0 && maxpatcount[pid])) continue;
+      if (!pid || (opt.count_cap > 0 && maxpatcount[pid])) continue;
       const pm_alignment &pa = al[j];
-      if (pa.editdist < 0 || pa.editdist > opt.nmismatch) {      // "Bogus hit" (primer_match.cc:1249-1263)
+      if (pa.editdist < 0 || pa.editdist > opt.max_edits) {      // "Bogus hit" (primer_match.cc:1249-1263)
         fprintf(stderr, "Bogus hit returned to primer_match main()\n");
-        if (opt.alignments) fprintf(stderr, "Problem sequence is near:\n>%s\n", db.get_header_data(l[j].key).header.c_str());
+        if (opt.print_hits) fprintf(stderr, "Problem sequence is near:\n>%s\n", db.get_header_data(l[j].key).header.c_str());
         else fprintf(stderr, "Approximate absolute sequence position:\n %lld\n", (long long)l[j].key);
         fprintf(stderr, "Problem primer:\n %s\n", patarray[pid].c_str());
         return 1;
       }
-      if (opt.alignments) {
+      if (opt.print_hits) {
         const long long length = pa.end - pa.start + 1;           // pattern_alignment::length (pattern_alignment.h:96-99)
         const long long p = pa.end;
         const long long spe = db.get_seq_pos(p), sps = spe - length + 1, pe = pa.end, ps = pe - length + 1;
@@ -418,20 +424,20 @@ int main(int argc, char **argv) {
         AlignFields a;
         a.s = sps; a.e = spe; a.five = rc ? spe : sps; a.three = rc ? sps : spe; a.S = ps; a.E = pe;
         a.i = ind; a.d = (unsigned)pa.editdist; a.p = patarray[ind];
-        a.P = opt.fasta_pattern_file ? patdefarray[ind] : std::string();
+        a.P = opt.primers_from_fasta ? patdefarray[ind] : std::string();
         a.q = patarray[pid]; a.Q = with_gaps(patarray[pid], ops, '^');
         a.r = rc ? "R" : "F"; a.R = rc ? " REVCOMP" : "";
         a.t = mt; a.T = with_gaps(mt, ops, 'v'); a.A = ops;
         a.h = h.header; a.H = h.short_header; a.f = h.index;
-        a.sts = opt.sts_pattern_file ? &stsarray[(ind + 1) / 2] : &null_sts;
-        alignformat(out, opt.alignformat, a);
+        a.sts = opt.primers_from_sts ? &stsarray[(ind + 1) / 2] : &null_sts;
+        alignformat(out, opt.hit_format, a);
       }
-      if (opt.counts) {
+      if (opt.print_tallies) {
         patcount[cidx(pid, (unsigned)pa.editdist)]++;
-        if (opt.maxcount > 0) {
+        if (opt.count_cap > 0) {
           unsigned long count = 0;
           for (unsigned k = 0; k < K1; ++k) count += patcount[cidx(pid, k)];
-          if (count >= (unsigned)opt.maxcount) maxpatcount[pid] = true;
+          if (count >= (unsigned)opt.count_cap) maxpatcount[pid] = true;
         }
       }
     }
@@ -439,26 +445,26 @@ int main(int argc, char **argv) {
     ff.pos(oldcharspos);
     t_report += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count();
   }
-  if (opt.verbose) fprintf(stderr, "scan (find_patterns) %.3f s, re-align + report %.3f s, %lu hits\n", t_scan, t_report, nhits);
+  if (opt.chatty) fprintf(stderr, "scan (find_patterns) %.3f s, re-align + report %.3f s, %lu hits\n", t_scan, t_report, nhits);
   ph.mark("Scanned sequence database");
 
   // ---- counts (primer_match.cc:1270-1328) ---------------------------------------------------
-  if (opt.counts) {
+  if (opt.print_tallies) {
     std::vector<unsigned long> counts(K1);
     for (unsigned long i = 1; i <= n; ++i) {
       unsigned long total = 0;
       for (unsigned k = 0; k < K1; ++k) { counts[k] = patcount[cidx(i, k)]; total += counts[k]; }
-      bool gtmax = opt.maxcount > 0 ? (bool)maxpatcount[i] : false;
-      const std::string patdef = opt.fasta_pattern_file ? patdefarray[i] : std::string();
-      const StsEntry &stsref = opt.sts_pattern_file ? stsarray[(i + 1) / 2] : null_sts;
-      if (!opt.aggregate) countformat(out, opt.countformat, i, patarray[i], patdef, patarray[i], "F", "", total, counts, (unsigned)opt.nmismatch, gtmax, stsref);
-      if (opt.rev_comp) {
-        if (!opt.aggregate) { total = 0; std::fill(counts.begin(), counts.end(), 0ul); gtmax = false; }
+      bool gtmax = opt.count_cap > 0 ? (bool)maxpatcount[i] : false;
+      const std::string patdef = opt.primers_from_fasta ? patdefarray[i] : std::string();
+      const StsEntry &stsref = opt.primers_from_sts ? stsarray[(i + 1) / 2] : null_sts;
+      if (!opt.merge_tallies) countformat(out, opt.tally_format, i, patarray[i], patdef, patarray[i], "F", "", total, counts, (unsigned)opt.max_edits, gtmax, stsref);
+      if (opt.both_strands) {
+        if (!opt.merge_tallies) { total = 0; std::fill(counts.begin(), counts.end(), 0ul); gtmax = false; }
         for (unsigned k = 0; k < K1; ++k) { counts[k] += patcount[cidx(i + n, k)]; total += patcount[cidx(i + n, k)]; }
-        if (opt.maxcount > 0) gtmax = gtmax || maxpatcount[i + n];
-        if (!opt.aggregate) countformat(out, opt.countformat, i, patarray[i], patdef, patarray[i + n], "R", " REVCOMP", total, counts, (unsigned)opt.nmismatch, gtmax, stsref);
+        if (opt.count_cap > 0) gtmax = gtmax || maxpatcount[i + n];
+        if (!opt.merge_tallies) countformat(out, opt.tally_format, i, patarray[i], patdef, patarray[i + n], "R", " REVCOMP", total, counts, (unsigned)opt.max_edits, gtmax, stsref);
       }
-      if (opt.aggregate) countformat(out, opt.countformat, i, patarray[i], patdef, "", "", "", total, counts, (unsigned)opt.nmismatch, gtmax, stsref);
+      if (opt.merge_tallies) countformat(out, opt.tally_format, i, patarray[i], patdef, "", "", "", total, counts, (unsigned)opt.max_edits, gtmax, stsref);
     }
   }
   out.flush();

@@ -23,13 +23,15 @@ ABI_SYMBOLS = [
     "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
+    "pm_final_hits_device", "pm_copy_records", "pm_pack_time",
 ]
 
 
 class PmError(RuntimeError):
-    def __init__(self, code, msg):
+    def __init__(self, code, msg, required=0):
         super().__init__("pm_gpu error %d: %s" % (code, msg))
         self.code = code
+        self.required = required          # PM_E_OVERFLOW: the record count the buffer must hold
 
 
 class _Config(C.Structure):
@@ -92,6 +94,9 @@ def load_library():
         L.pm_last_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.pm_pick_semantics.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pm_measure_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        L.pm_final_hits_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.pm_copy_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pm_pack_time.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -237,25 +242,37 @@ class PatternMatch:
         self._check(self._L.pm_set_capacity(self._h, n))
 
     def scan_candidates(self, begin, end, to_host=True):
+        """Device stage over (begin, end]; the record buffer grows (and the range is scanned again)
+        when it was too small.  Returns the records (host array) or, with to_host=False, their count."""
         n_out = C.c_size_t()
         rc = self._L.pm_scan_candidates(self._h, begin, end, None, 0, C.byref(n_out))
-        if rc == PM_E_OVERFLOW:
+        while rc == PM_E_OVERFLOW:
             self.set_capacity(int(n_out.value * 1.25) + 1024)
             rc = self._L.pm_scan_candidates(self._h, begin, end, None, 0, C.byref(n_out))
         self._check(rc)
         if not to_host:
             return n_out.value
-        out = np.zeros(n_out.value, dtype=HIT_DTYPE)
-        if n_out.value:
-            self._check(self._L.pm_scan_candidates(self._h, begin, end, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+        ptr, n = self.candidates_device()
+        return self.copy_records(ptr, n)
+
+    def copy_records(self, d_ptr, n):
+        """n 16-byte records from HBM (pm_copy_records)."""
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        if n:
+            self._check(self._L.pm_copy_records(self._h, C.c_void_p(d_ptr), n, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def scan_async(self, begin, end):
         self._check(self._L.pm_scan_candidates_async(self._h, begin, end))
 
     def scan_wait(self):
+        """Raises PmError(PM_E_OVERFLOW) with .required set when the record buffer was too small:
+        set_capacity(required * 1.25) and scan the range again."""
         n_out = C.c_size_t()
-        self._check(self._L.pm_scan_wait(self._h, C.byref(n_out)))
+        rc = self._L.pm_scan_wait(self._h, C.byref(n_out))
+        if rc == PM_E_OVERFLOW:
+            raise PmError(rc, (self._L.pm_last_error(self._h) or b"").decode(), required=n_out.value)
+        self._check(rc)
         return n_out.value
 
     def candidates_device(self):
@@ -272,24 +289,32 @@ class PatternMatch:
                                         out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
         return out[:n_out.value]
 
-    def finalize_device(self, scanned_to, last=True, sort=True, d_cands=None, n=0, out=None, owned=None):
+    def finalize_device(self, scanned_to, last=True, sort=True, d_cands=None, n=0, out=None, owned=None, keep=False):
         """GPU clustering of the records of the last scan (or of `d_cands`, a device pointer);
         returns the final hits (host array).  Raises PmError(-2) where only the host stage applies.
         owned=(own_lo, own_hi, guard_lo, guard_hi): this call is one shard of a position-sharded
-        scan (pm_finalize_device_owned); guard_hi=None declares the true end of the stream."""
-        if out is None:
-            cap = max(n if d_cands else self.candidates_device()[1], 1) + 1024
-            out = np.empty(cap, dtype=HIT_DTYPE)
+        scan (pm_finalize_device_owned); guard_hi=None declares the true end of the stream.
+        keep=True: the hits stay in HBM; returns (device pointer, count) (pm_final_hits_device)."""
+        if keep:
+            optr, ocap, sort = C.c_void_p(0), 0, False
+        else:
+            if out is None:
+                cap = max(n if d_cands else self.candidates_device()[1], 1) + 1024
+                out = np.empty(cap, dtype=HIT_DTYPE)
+            optr, ocap = out.ctypes.data_as(C.c_void_p), out.size
         n_out = C.c_size_t()
         if owned is not None:
             own_lo, own_hi, guard_lo, guard_hi = owned
             self._check(self._L.pm_finalize_device_owned(self._h, C.c_void_p(d_cands or 0), n, own_lo, own_hi, guard_lo,
                                                          (1 << 63) - 1 if guard_hi is None else guard_hi, 2 if sort else 0,
-                                                         out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
-            return out[:n_out.value]
-        self._check(self._L.pm_finalize_device(self._h, C.c_void_p(d_cands or 0), n, scanned_to,
-                                               (1 if last else 0) | (2 if sort else 0),
-                                               out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+                                                         optr, ocap, C.byref(n_out)))
+        else:
+            self._check(self._L.pm_finalize_device(self._h, C.c_void_p(d_cands or 0), n, scanned_to,
+                                                   (1 if last else 0) | (2 if sort else 0), optr, ocap, C.byref(n_out)))
+        if keep:
+            p, cnt = C.c_void_p(), C.c_size_t()
+            self._check(self._L.pm_final_hits_device(self._h, C.byref(p), C.byref(cnt)))
+            return p.value or 0, cnt.value
         return out[:n_out.value]
 
     def align_hits(self, hits):
@@ -307,6 +332,11 @@ class PatternMatch:
         buf = C.create_string_buffer(512)
         self._check(self._L.pm_describe(self._h, buf, 512))
         return buf.value.decode()
+
+    def pack_time(self):
+        ms = C.c_float()
+        self._check(self._L.pm_pack_time(self._h, C.byref(ms)))
+        return ms.value
 
     def last_kernel_time(self):
         ms, n = C.c_float(), C.c_int()

@@ -1,0 +1,68 @@
+"""GPU: the multi-rank path that ships -- bench.py itself -- rehearsed with two ranks on one card.
+
+SURVEY.md 8(e): the stream is sharded by position, every rank scans its shard (+ guard band), the
+final hit records (filter_bitvec option sets: clustered and verified on the owning rank) or the
+candidate records (the rest) are gathered to rank 0.  Here bench.py is launched exactly as the
+driver launches it (`python -m torch.distributed.run ... bench.py --gpus 2`), with the collectives
+on gloo because the box has one GPU (PM_BENCH_BACKEND=gloo; with RCCL the same code gathers device
+buffers), and its final hit list must equal the single-rank run's, which in turn must hold every
+planted primer site (bench.py checks that itself and fails otherwise).  The serial rule the shards
+must reproduce: filter_bitvec.cc:88-177 (one hit per chain of candidates), exact_halves.cc:140-190.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DB = 50_000_000
+PRIMERS = 20_000
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(ranks, k, indels, dump, extra=()):
+    common = ["bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--db-bases", str(DB), "--primers", str(PRIMERS),
+              "--k", str(k), "--indels", str(indels), "--scaling", "strong", "--no-cpu", "--dump-hits", dump, *extra]
+    env = dict(os.environ, PM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ranks == 1:
+        cmd = [sys.executable] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + common
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line), np.load(dump)
+
+
+@pytest.mark.parametrize("k,indels", [(2, 0), (2, 1), (0, 0), (1, 0), (1, 1)])
+def test_two_ranks_equal_one_rank(tmp_path, k, indels):
+    j1, h1 = run_bench(1, k, indels, str(tmp_path / "one.npy"))
+    j2, h2 = run_bench(2, k, indels, str(tmp_path / "two.npy"))
+    assert j1["ranks_seen"] == 1 and j2["ranks_seen"] == 2 and j2["n_gpus"] == 2
+    assert j1["config"]["planted_found"] is not None and j2["config"]["planted_found"] == j1["config"]["planted_found"]
+    assert h1.size > 0
+    assert h1.size == h2.size and (h1 == h2).all(), (h1.size, h2.size)
+    assert j2["config"]["final_hits"] == h2.size
+
+
+@pytest.mark.parametrize("k,indels", [(2, 0), (0, 0)])
+def test_two_ranks_grow_and_rescan_after_overflow(tmp_path, k, indels):
+    """a record buffer that is too small on every rank: the ranks agree to grow it and scan again
+    (no rank is left waiting in the gather), and the result does not change"""
+    j1, h1 = run_bench(1, k, indels, str(tmp_path / "one.npy"))
+    j2, h2 = run_bench(2, k, indels, str(tmp_path / "two.npy"), extra=("--capacity", "64"))
+    assert j2["config"]["rescans_after_overflow"] >= 1
+    assert h1.size == h2.size and (h1 == h2).all()
+    j3, h3 = run_bench(1, k, indels, str(tmp_path / "three.npy"), extra=("--capacity", "64"))
+    assert j3["config"]["rescans_after_overflow"] >= 1 and (h1 == h3).all()
