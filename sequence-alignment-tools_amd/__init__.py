@@ -10,7 +10,7 @@ library is the in-tree HIP build (csrc/libpm_gpu.so); there is no CPU fallback -
 or a gfx950 device is missing, calls fail loudly.
 """
 from .pattern_match import (  # noqa: F401
-    HIT_DTYPE, KERNEL_AUTO, KERNEL_BITPAR, KERNEL_SEED, SEM_AUTO, SEM_EXACT_BASES, SEM_EXACT_HALVES,
+    HIT_DTYPE, PM_E_OVERFLOW, KERNEL_AUTO, KERNEL_BITPAR, KERNEL_SEED, SEM_AUTO, SEM_EXACT_BASES, SEM_EXACT_HALVES,
     SEM_FILTER_BITVEC, SEM_KEYWORD_TREE, SEM_SHIFT_AND, SEM_SHIFT_AND_INEXACT, PatternMatch, PmError,
     build_library, library_path, load_library, measure_stream_read, pick_semantics, reverse_comp, sorted_tuples,
 )

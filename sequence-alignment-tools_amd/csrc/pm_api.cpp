@@ -21,6 +21,7 @@
 #include "pm_internal.h"
 #include "pm_iupac.h"
 #include "pm_seed.h"
+#include "pm_pair.h"
 
 using namespace pm;
 
@@ -57,12 +58,15 @@ struct pm_handle {
   BitparDevice bp;
   SeedDevice sd;                      // first pattern tile (plan parameters are read from here)
   std::vector<SeedDevice> sd_more;    // further tiles when the pattern set is too large for one LDS filter
+  std::vector<PairDevice> pair;       // -K 1 / -K 2 on 20..32 character patterns: the pair plan's tiles (pm_pair.hip) instead of sd
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
   bool edits_dev = false;             // filter_bitvec / shift_and_inexact -k on the seed kernels: records deduplicated after the scan
   unsigned long long *d_seed_count = nullptr;   // edits: [0] unused, [1+t] seed records of tile t
   uint64_t *d_seeds = nullptr;                  // edits: 8-byte seed records between the scan and the verify kernel
   size_t seed_cap = 0;
+  void *d_susp = nullptr;                       // pair plan: 16-byte suspect records between its scan and verify kernels
+  size_t susp_cap = 0;
   unsigned long long h_seed_count[1 + 256] = {};
   std::vector<pm_hit> start_cache;    // edits: candidates that end in the first Lw+2k+2 characters (whole-prefix scans only)
   bool start_cached = false;
@@ -189,9 +193,11 @@ static void free_device(pm_handle *h) {
   seed_free(&h->sd);
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
+  for (PairDevice &d : h->pair) pair_free(&d);
+  h->pair.clear();
   if (h->d_cands) (void)hipFree(h->d_cands);
-  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb, h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_seed_count, h->d_seeds}; for (void *q : hx) if (q) (void)hipFree(q); }
-  h->d_seed_count = nullptr; h->d_seeds = nullptr;
+  { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb, h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_seed_count, h->d_seeds, h->d_susp}; for (void *q : hx) if (q) (void)hipFree(q); }
+  h->d_seed_count = nullptr; h->d_seeds = nullptr; h->d_susp = nullptr; h->susp_cap = 0;
   h->d_dp_codes = nullptr; h->d_dp_esb = h->d_dp_eeb = nullptr;
   h->d_ext = nullptr; h->d_half_codes = h->d_half_len = nullptr; h->d_hesb = h->d_heeb = nullptr;
   if (h->d_counter) (void)hipFree(h->d_counter);
@@ -331,6 +337,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   bitpar_free(&h->bp); seed_free(&h->sd);
   for (SeedDevice &d : h->sd_more) seed_free(&d);
   h->sd_more.clear();
+  for (PairDevice &d : h->pair) pair_free(&d);
+  h->pair.clear();
   // tables pm_finalize_device builds on first use depend on the alphabet mapping and the pattern
   // list of THIS init: drop the ones of an earlier init
   { void *lazy[] = {h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_fpat_len, h->d_fpat_id}; for (void *q : lazy) if (q) (void)hipFree(q); }
@@ -394,7 +402,29 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
     size_t per = (sp.size() + ntile - 1) / ntile;
     if (halves_mode) per += per & 1;                // keep (left, right) half pairs together: side = index parity
-    for (size_t ti = 0; ti < ntile && why.empty(); ++ti) {
+    // Substitution-only search with k = 1, 2 on patterns of 20..32 characters: the pair plan (exact
+    // 20-bit key bitmaps, pm_pair.hip) replaces the Bloom-filter plan of pm_seed.hip
+    bool use_pair = !halves_mode && !edits_mode && (sk == 1 || sk == 2) && !sp.empty() && force_lw >= 20;
+    if (const char *env = getenv("PM_PAIR")) use_pair = use_pair && atoi(env) != 0;
+    for (size_t ti = 0; ti < ntile && why.empty() && use_pair; ++ti) {
+      const size_t lo = ti * per, hi = std::min(sp.size(), lo + per);
+      std::vector<Pattern> tp(sp.begin() + lo, sp.begin() + hi);
+      std::vector<uint32_t> tid(sid.begin() + lo, sid.begin() + hi);
+      PairTables pt;
+      const std::string msg = pair_build(tp, tid, h->alpha, sk, h->eos_code, &pt);
+      if (!msg.empty()) {                                            // not for this set: the seed plan below takes it
+        for (PairDevice &d : h->pair) pair_free(&d);
+        h->pair.clear();
+        use_pair = false;
+        break;
+      }
+      h->pair.emplace_back();
+      HIP_TRY(h, pair_upload(pt, &h->pair.back(), h->stream));
+      // the plan facts the rest of this file reads from h->sd (no device tables behind them)
+      h->sd.k = sk; h->sd.Lw = 20; h->sd.pb = 5; h->sd.r = 4 - sk; h->sd.ncombos = pt.ncombos; h->sd.ascii = pt.ascii;
+      h->sd.maxlen = std::max(h->sd.maxlen, pt.maxlen);
+    }
+    for (size_t ti = 0; ti < ntile && why.empty() && !use_pair; ++ti) {
       const size_t lo = ti * per, hi = std::min(sp.size(), lo + per);
       std::vector<Pattern> tp(sp.begin() + lo, sp.begin() + hi);
       std::vector<uint32_t> tid(sid.begin() + lo, sid.begin() + hi);
@@ -617,7 +647,15 @@ extern "C" int pm_selected_kernel(const pm_handle *h) { return h && h->inited ? 
 
 extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   if (!h || !buf || !h->inited) return PM_E_INVALID;
-  if (h->kern == PM_KERNEL_SEED) {
+  if (h->kern == PM_KERNEL_SEED && !h->pair.empty()) {
+    snprintf(buf, buflen, "kernel=pm_pair_scan tiles=%d combos=%d fields=2-of-4 x 5 bases window=20 chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
+             (int)h->pair.size(), h->pair[0].ncombos, (long long)h->geo.seg_len, h->geo.nseg, h->geo.blocks, h->geo.threads, PAIR_LDS_BYTES);
+    if (h->nrest) {
+      const size_t at = strlen(buf);
+      if (at < buflen) snprintf(buf + at, buflen - at, " + %s for %zu patterns the seed plan does not take", bitpar_kernel_name(h->scan_k, h->scan_indels), h->nrest);
+    }
+  }
+  else if (h->kern == PM_KERNEL_SEED) {
     snprintf(buf, buflen, "kernel=pm_seed_scan tiles=%d combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
              1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
              h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
@@ -663,6 +701,27 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->last_launches = 2 * ntiles;
+    if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
+  }
+  else if (h->kern == PM_KERNEL_SEED && !h->pair.empty())
+  {
+    // suspects (windows within k of a pattern on the packed bases, before the exact check): a few per
+    // thousand positions on random streams; a denser stream overflows once and the buffer grows
+    // (+ up to 15 unused slots per wave of the scan grid: slots are reserved 16 at a time)
+    const size_t want = (size_t)((end - begin) / 128) + (size_t)((end - begin) / 8192) * h->pair[0].ncombos + ((size_t)1 << 20);
+    if (!h->d_susp || h->susp_cap < want) {
+      if (h->d_susp) { (void)hipFree(h->d_susp); h->d_susp = nullptr; }
+      h->susp_cap = std::max(h->susp_cap, want);
+      HIP_TRY(h, hipMalloc(&h->d_susp, h->susp_cap * PAIR_SUSPECT_BYTES));
+    }
+    if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, (1 + 256) * sizeof(unsigned long long)));
+    if (h->pair.size() > 256) return fail(h, PM_E_UNSUPPORTED, "too many pattern tiles");
+    HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, (1 + 256) * sizeof(unsigned long long), h->stream));
+    for (size_t t = 0; t < h->pair.size(); ++t)
+      HIP_TRY(h, pair_launch(h->pair[t], h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap,
+                             h->d_susp, h->d_seed_count + 1 + t, h->susp_cap, h->stream, t == 0 ? &h->geo : nullptr));
+    HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    h->last_launches = 2 * (int)h->pair.size();
     if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }
   else if (h->kern == PM_KERNEL_SEED)
@@ -814,6 +873,19 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     h->last_count = (size_t)*h->h_counter;
     if (n_out) *n_out = h->last_count;
     h->last_launches += 1;
+  }
+  if (h->kern == PM_KERNEL_SEED && !h->pair.empty()) {
+    // the suspect buffer must have held every tile's suspects
+    unsigned long long worst = 0;
+    for (size_t t = 0; t < h->pair.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] pair plan: %llu suspects (tile with most), capacity %zu, candidates %zu\n", worst, h->susp_cap, cnt);
+    if (worst > h->susp_cap) {                                     // grow it and tell the caller to scan again
+      (void)hipFree(h->d_susp); h->d_susp = nullptr;
+      h->susp_cap = (size_t)worst + (size_t)worst / 8 + 1024;
+      h->last_count = 0;
+      if (n_out) *n_out = std::max<size_t>(cnt, h->cap) + 1;         // "> cap": the callers' grow-and-rescan condition
+      return fail(h, PM_E_OVERFLOW, "suspect buffer was too small; it has been enlarged, scan the range again");
+    }
   }
   if (h->edits_dev) {
     // the seed buffer of a tile must have held all its seed records

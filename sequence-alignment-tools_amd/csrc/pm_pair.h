@@ -1,0 +1,73 @@
+// pm_pair.h -- "pair plan" scan kernel (pm_pair.hip): host tables and launch interface.
+//
+// Substitution-only candidates (-K 1, -K 2) of 20..32 character A,C,G,T patterns.  The last 20
+// bases of a pattern are cut into four fields of five bases (10 bits of the 2-bit packed window);
+// <= 2 substitutions leave two fields untouched (<= 1: the first two or the last two), so every
+// candidate agrees with its pattern on one of the C(4,2) = 6 field pairs (2 for k = 1).  A pair of
+// fields is a 20-bit key: 2^20 keys are exactly the bits of a 128 KiB LDS bitmap, so the first
+// stage is an exact membership test (one v_alignbit, one ds_read_b32, one shift) instead of a
+// hashed Bloom filter, and it runs over 6 (2) combos instead of the 10 (4) of the byte-piece plan.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pm_internal.h"
+
+namespace pm {
+
+constexpr int PAIR_THREADS = 1024;                  // 16 waves, one workgroup per CU (LDS bound)
+constexpr int PAIR_WAVES = PAIR_THREADS / 64;
+constexpr int PAIR_MAX_COMBOS = 6;
+constexpr int PAIR_BITMAP_WORDS = 32768;            // 2^20 key bits
+constexpr int PAIR_SUPER = 512;                     // u32 rank before every 2048-bit superblock
+constexpr int PAIR_REL_WORDS = 2048;                // 4096 x u16: rank of a 256-bit block inside its superblock
+constexpr int PAIR_IMAGE_WORDS = PAIR_BITMAP_WORDS + PAIR_SUPER + PAIR_REL_WORDS;   // staged per (combo, chunk)
+constexpr int PAIR_QREGION = 64;                    // per wave: two queue regions of suspicious windows (8-byte entries), one filling, one in flight
+constexpr int PAIR_LDS_BYTES = PAIR_IMAGE_WORDS * 4 + PAIR_WAVES * 2 * PAIR_QREGION * 8;
+static_assert(PAIR_LDS_BYTES <= 163840, "160 KiB of LDS per workgroup");
+
+struct PairTables {                                 // one pattern tile
+  int k = 0, maxlen = 0, ncombos = 0, eos_code = -1;
+  bool ascii = false;
+  int fa[PAIR_MAX_COMBOS] = {}, fb[PAIR_MAX_COMBOS] = {};   // key fields of every combo (a < b), the other two are (c < d)
+  std::vector<uint32_t> image;                      // [combo][PAIR_IMAGE_WORDS]
+  std::vector<uint32_t> entries;                    // [combo][2 * distinct keys]: see pm_pair.hip
+  std::vector<int16_t> direct;                      // [combo][2^20]: direct-mapped by key, six bases of the first pattern | 0x8000 = several
+  std::vector<uint32_t> first_pat;                  // [combo][distinct keys + 1]: first index into order[] of every key
+  std::vector<uint32_t> order;                      // [combo][np]: pattern indices sorted by key
+  size_t entries_off[PAIR_MAX_COMBOS] = {}, first_off[PAIR_MAX_COMBOS] = {};   // per combo, in elements of the arrays above
+  std::vector<uint64_t> pat40;                      // last 20 bases, 2 bits each
+  std::vector<uint8_t> pat_len;
+  std::vector<uint32_t> pat_id;
+  std::vector<uint8_t> pat_codes;                   // 32 stream codes per pattern
+};
+
+struct PairDevice {
+  int k = 0, maxlen = 0, ncombos = 0, eos_code = -1;
+  bool ascii = false;
+  int fa[PAIR_MAX_COMBOS] = {}, fb[PAIR_MAX_COMBOS] = {};
+  size_t entries_off[PAIR_MAX_COMBOS] = {}, first_off[PAIR_MAX_COMBOS] = {};
+  size_t np = 0;
+  int16_t *direct = nullptr;
+  uint32_t *image = nullptr, *entries = nullptr, *first_pat = nullptr, *order = nullptr, *pat_id = nullptr;
+  uint64_t *pat40 = nullptr;
+  uint8_t *pat_len = nullptr, *pat_codes = nullptr;
+};
+
+// "" or why the plan does not take this pattern set
+std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids, const Alphabet &alpha, int k,
+                       int eos_code, PairTables *out);
+hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st);
+void pair_free(PairDevice *d);
+ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end);
+// d_susp: susp_cap 16-byte suspect records between the scan kernel and pm_pair_verify; *d_susp_count is
+// zeroed by the caller before the launch and holds the number of suspects afterwards (> susp_cap: the
+// buffer was too small and the candidate records are incomplete)
+constexpr size_t PAIR_SUSPECT_BYTES = 16;
+hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
+                       pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, void *d_susp, unsigned long long *d_susp_count, uint64_t susp_cap,
+                       hipStream_t st, ScanGeometry *geo_out);
+
+}  // namespace pm
