@@ -1,5 +1,5 @@
-// pm_pair.hip -- "pair plan" scan kernel for gfx950: exact 20-bit key bitmap in LDS, survivors
-// resolved by rank into a dense per-key table in L2.
+// pm_pair.hip -- "pair plan" scan kernels for gfx950: exact 20-bit key bitmap in LDS, a direct-mapped
+// 2-byte table in L2 for the keys that occur, rank-indexed exact table for the few windows left.
 //
 // What it computes: every (end, pattern, d) with d = Hamming(stream window, pattern) <= k, k = 1 or 2,
 // and no EOS inside the window -- the candidate set of the reference's substitution-only k-error
@@ -11,25 +11,34 @@
 // leave >= 2 fields untouched: the window agrees with the pattern on one of the 6 field pairs
 // (k = 1: on fields {0,1} or {2,3}).  A field pair is a 20-bit key, and 2^20 key bits are exactly a
 // 128 KiB bitmap:
-//   * a WORKGROUP owns one (field pair, stream chunk): it stages that pair's key bitmap and its rank
-//     directory in LDS, then streams its chunk of the 2-bit packed stream;
-//   * a LANE owns 16 consecutive window positions per block of 1024; the block's packed dwords go
-//     through a small per-wave LDS ring (which also hands every lane its two predecessors' dwords).
-//     Test of a window whose fields are adjacent: one v_alignbit (the key, pre-shifted by 2), one
-//     v_and (LDS byte address: key bits 0..14 select the word), one ds_read_b32, two shifts (key
-//     bits 15..19 select the bit; verdict funnelled into a 16-bit mask) -- 5 VALU + 1 LDS; field
-//     pairs that are apart take a second v_alignbit and a v_bfi;
-//   * survivors (a key of the pattern set really occurs: ~17 % of the tests at 200k patterns) are
-//     compacted per wave with ballot + mbcnt as 16-bit (ring dword, window) entries.  A full
-//     queue -- and the end of every block -- is drained by whole waves: the window is cut out of the
-//     ring again, the key's RANK among the set bits of the bitmap (two-level directory + popcounts,
-//     all in LDS) indexes a dense table with one 8-byte entry per distinct key: the remaining 20
-//     window bits of up to two patterns that have this key.  That load is consumed one drain later,
-//     so its L2 round trip is never waited for: XOR + popcount against the window's other two
-//     fields, and only the few pairs within k substitutions there (1e-4 of the survivors) read the
-//     raw stream bytes for the exact distance (N = mismatch, EOS = reject);
+//   * a WORKGROUP owns one (field pair, stream chunk): it stages that pair's key bitmap (and a rank
+//     directory over it) in LDS, then streams its chunk of the 2-bit packed stream;
+//   * a LANE owns 16 consecutive window positions per block of 1024; its two predecessors' dwords
+//     come in by two whole-wave DPP shifts.  Everything that runs for every window is straight-line
+//     code with compile-time window offsets:
+//       test     one v_alignbit (the key, pre-shifted by 2; field pairs that are apart: a second one
+//                and a v_bfi), one v_and (LDS byte address: key bits 0..14 select the word), one
+//                ds_read_b32, two shifts (key bits 15..19 select the bit; verdict funnelled into a
+//                16-bit mask), then one 2-byte load from the pair's direct-mapped table in L2 (2 MiB,
+//                index = key): six bases of the first pattern that has the key and a "several patterns
+//                share this key" bit.  Windows whose key does not occur (83 % at 200k patterns) read
+//                entry 0 -- one cached line for all of them -- so the load needs no branch;
+//       consume  one block later, when the loads have landed: XOR + popcount of those six bases
+//                against the window's other fields.  ~2 % of the windows stay suspicious;
+//   * those are compacted per wave (ballot + mbcnt) into an LDS queue and resolved 64 at a time: the
+//     key's RANK among the set bits of the bitmap (two-level directory + popcounts, all in LDS)
+//     indexes a dense table with one 8-byte slot per distinct key -- the other 20 window bits of up
+//     to three patterns -- whose load is consumed one batch later (XOR + popcount on all 20 bits);
+//   * what is still within k there (1e-3 of the positions) goes to a suspect list; a second kernel,
+//     pm_pair_verify, reads the raw stream bytes for the exact distance (N = mismatch, EOS = reject)
+//     with every lane busy;
 //   * a (window, pattern) pair that agrees on several field pairs is reported by the first of them
 //     in the plan's list.
+//
+// Bounds (3 Gbp, 200k patterns, k = 2; PM_SEED_DEBUG stage switches, scripts/pair_stages.sh): the
+// straight-line part is LDS-bank-conflict and VALU bound (8.5 ms for 1.8e10 tests: 5 + 4 + 9 VALU per
+// test, random ds_read_b32 ~7 cycles per wave instruction), the 3.1e9 direct-table lookups add 4.9 ms
+// (the L1 fill path moves one 128-byte line per lookup), the suspicious 2 % another 4 ms.
 #include "pm_internal.h"
 #include "pm_pair.h"
 
@@ -339,7 +348,6 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t q2 = ws + 2048 < own_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
   uint32_t q3 = ws + 3072 < own_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
 
-  const uint32_t dbg_mask = (a.debug & 8) ? 0u : 0xffffffffu;      // measurement: every direct-table load reads entry 0
   // consume stage of half a block (windows 8H .. 8H+7 of the block whose stream words are v2 : v1 : vc):
   // its table entries E have landed.  Returns the suspicious windows, bit j = window 8H + j.
   auto consume = [&](auto HALF, uint32_t v2, uint32_t v1, uint32_t vc, const int32_t (&E)[8]) __attribute__((always_inline)) -> uint32_t {
@@ -418,23 +426,31 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const uint32_t v = wd[j] >> ((ks[j] >> 17) & 31u);            // bits 15..19 of the key pick the bit
       acc = __builtin_amdgcn_alignbit(v, acc, 1);
       // table index = key for a survivor, 0 otherwise (byte offset 2 * key from the key at bits 2..21)
-      const uint32_t off = (ks[j] >> 1) & 0x1ffffeu & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1) & dbg_mask;
+      const uint32_t off = (ks[j] >> 1) & 0x1ffffeu & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1);
       E[j] = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(direct) + off);   // plain load: nontemporal ran 3x, sc1 1.7x slower
     }
   };
 
-  int32_t E0[8], E1[8];
+  // Software pipeline, one block deep: the entries a half block's test stage loads are consumed
+  // after the same half of the NEXT block has been tested -- about 300 instructions of this wave (and
+  // as many of each of the three other waves of its SIMD) later; with half a block of distance the
+  // table loads (the L1 fill path runs saturated: one 128-byte line per lookup) were still waited for.
+  // Block parity is compile time (two entry buffers per half, two sets of block state).
+  int32_t E[2][2][8];                                               // [block parity][half][window]
+  uint32_t sv2[2] = {0, 0}, sv1[2] = {0, 0}, svc[2] = {0, 0}, srem[2] = {0, 0};   // per parity: stream words, bitmap survivors
+  int64_t sbb[2] = {ws, ws};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { E0[i] = 0; E1[i] = 0; }
-  // software pipeline at half-block granularity: the entries a half's test stage loads are consumed
-  // after the other half's test stage, i.e. about 150 instructions of this wave (and as many of each
-  // of the three other waves of the SIMD) later
-  uint32_t pv2 = 0, pv1 = 0, pvc = 0, prem_hi = 0, slow_lo = 0;      // block before: stream words, bitmap survivors of its second half, suspects of its first
-  int64_t pbb = ws;
-  bool have_prev = false;                                           // wave-uniform
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) E[q][hh][i] = 0;
   const std::integral_constant<int, 0> H0;
   const std::integral_constant<int, 1> H1;
-  for (int64_t bb = ws; bb < own_hi; bb += 1024) {
+  int64_t bb = ws;
+  bool have_prev = false;                                           // wave-uniform
+  auto block = [&](auto PAR) __attribute__((always_inline)) {
+    constexpr int P = decltype(PAR)::value, O = P ^ 1;
     const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
     if (bb + 4096 < own_hi) q3 = load_packed(a.packed, a.npacked, bb + 4096 + 16 * lane);
@@ -450,20 +466,34 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
       own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
     }
-    uint32_t acc = 0;
-    test(H0, prev2, prev1, cur, E0, acc);
-    if (have_prev) {                                                // second half of the block before, then that block's suspects
-      const uint32_t slow_hi = consume(H1, pv2, pv1, pvc, E1) & prem_hi;
-      compact(pv2, pv1, pvc, pbb, slow_lo | (slow_hi << 8));
+    uint32_t acc = 0, slow = 0;
+    test(H0, prev2, prev1, cur, E[P][0], acc);
+    if (have_prev) slow = consume(H0, sv2[O], sv1[O], svc[O], E[O][0]);
+    test(H1, prev2, prev1, cur, E[P][1], acc);
+    if (have_prev) {
+      slow |= consume(H1, sv2[O], sv1[O], svc[O], E[O][1]) << 8;
+      compact(sv2[O], sv1[O], svc[O], sbb[O], slow & srem[O]);
     }
-    test(H1, prev2, prev1, cur, E1, acc);
-    const uint32_t rem = (acc >> 16) & own;
-    slow_lo = consume(H0, prev2, prev1, cur, E0) & rem & 0xffu;
-    pv2 = prev2; pv1 = prev1; pvc = cur; prem_hi = rem >> 8; pbb = bb; have_prev = true;
+    sv2[P] = prev2; sv1[P] = prev1; svc[P] = cur; srem[P] = (acc >> 16) & own; sbb[P] = bb;
+    have_prev = true;
+    bb += 1024;
+  };
+  const std::integral_constant<int, 0> P0;
+  const std::integral_constant<int, 1> P1;
+  bool last_odd = false;                                            // parity of the last block tested
+  while (bb < own_hi) {
+    block(P0); last_odd = false;
+    if (bb >= own_hi) break;
+    block(P1); last_odd = true;
   }
-  if (have_prev) {
-    const uint32_t slow_hi = consume(H1, pv2, pv1, pvc, E1) & prem_hi;
-    compact(pv2, pv1, pvc, pbb, slow_lo | (slow_hi << 8));
+  if (have_prev) {                                                  // the last block's entries
+    if (last_odd) {
+      const uint32_t slow = consume(H0, sv2[1], sv1[1], svc[1], E[1][0]) | (consume(H1, sv2[1], sv1[1], svc[1], E[1][1]) << 8);
+      compact(sv2[1], sv1[1], svc[1], sbb[1], slow & srem[1]);
+    } else {
+      const uint32_t slow = consume(H0, sv2[0], sv1[0], svc[0], E[0][0]) | (consume(H1, sv2[0], sv1[0], svc[0], E[0][1]) << 8);
+      compact(sv2[0], sv1[0], svc[0], sbb[0], slow & srem[0]);
+    }
   }
   if (qn) drain();
   finish();
