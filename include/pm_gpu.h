@@ -185,6 +185,30 @@ int pm_align_hits(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out)
  * both NUL-terminated at ops + i*stride and text + i*stride.  stride > longest pattern + k. */
 int pm_align_hits_text(pm_handle *h, const pm_hit *hits, size_t n, pm_alignment *out, char *ops, char *text, size_t stride);
 
+/* ---- Multi-GPU exchange (the reference has no counterpart: its scan is one serial
+ * pass, primer_match.cc:1118).  One rank = one process = one GPU.  The ranks scan position shards
+ * (pm_scan_candidates on local stream indices), exchange their record counts by whatever means the
+ * launcher has, then gather the 16-byte records out of HBM into rank 0 over xGMI (RCCL send/recv;
+ * librccl.so is loaded on first use).  The unique id (PM_COMM_ID_BYTES) is made on rank 0 and handed
+ * to the other ranks by the launcher.  Errors: pm_comm_last_error (NULL = the last failed create). */
+#define PM_COMM_ID_BYTES 128
+typedef struct pm_comm pm_comm;
+int pm_comm_unique_id(void *id_out);
+int pm_comm_create(int device, int rank, int world, const void *id, pm_comm **out);
+/* counts[0..world): records every rank contributes (the same array on every rank).  Rank r sends
+ * d_send[0..n_send) (n_send == counts[r]); rank 0 receives all of them in rank order and copies the
+ * list to host_out (sum of counts records).  Collective: every rank of the communicator calls it. */
+int pm_comm_gather(pm_comm *c, const void *d_send, size_t n_send, const uint64_t *counts, pm_hit *host_out);
+void pm_comm_destroy(pm_comm *c);
+const char *pm_comm_last_error(const pm_comm *c);
+
+/* PatternMatch::init for a handle that only runs the HOST stage -- pm_finalize, pm_align_hits[_text]
+ * -- over the whole stream: the merge rank of a position-sharded scan, whose own GPU holds one shard
+ * only.  `text` (borrowed, n bytes, stays on the host) and `table` as for pm_init; the pattern tables
+ * are built as for pm_init (they decide what the shards' records mean), nothing of the stream is
+ * uploaded, and every scan entry point returns PM_E_INVALID. */
+int pm_init_host(pm_handle *h, const uint8_t *text, int64_t n, const uint8_t *table, int32_t table_len);
+
 /* PatternMatch::reset (pattern_match.h:134): forget scan state, keep patterns and text. */
 int pm_reset(pm_handle *h);
 void pm_destroy(pm_handle *h);

@@ -45,6 +45,7 @@ struct pm_handle {
   int eos_code = -1;
   int sem = 0, kern = 0;
   bool inited = false;
+  bool host_only = false;             // pm_init_host: host stage only, no stream on the device
 
   const uint8_t *h_text = nullptr;
   const uint8_t *d_text = nullptr;
@@ -330,7 +331,12 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   } else h->alpha.set_raw();
   // -w/-W on a raw stream: IUPAC classes name up to 16 letters each, the kernels keep 6 character
   // classes in registers -- only the letters that occur in the stream need one
-  if (!table && h->cfg.wildcards) HIP_TRY(h, stream_presence(h->d_text, h->n, h->alpha.present, h->stream));
+  if (!table && h->cfg.wildcards) {
+    if (h->host_only) {                                             // no device copy: look at the host bytes
+      for (int i = 0; i < 256; ++i) h->alpha.present[i] = false;
+      for (int64_t i = 0; i < h->n; ++i) h->alpha.present[h->h_text[i]] = true;
+    } else HIP_TRY(h, stream_presence(h->d_text, h->n, h->alpha.present, h->stream));
+  }
   h->eos_code = h->alpha.nch[(uint8_t)h->cfg.eos];                  // shift_and_inexact.cc:131
   int rc = resolve(h);
   if (rc) return rc;
@@ -502,7 +508,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
   if (!h->ev1) HIP_TRY(h, hipEventCreate(&h->ev1));
   if (!h->d_cands) { rc = ensure_capacity(h, (size_t)1 << 20); if (rc) return rc; }
-  if (h->edits_dev) {                                               // every candidate is reported by several seeds before the dedup
+  if (h->edits_dev && !h->host_only) {                              // every candidate is reported by several seeds before the dedup
     const size_t want = std::min<size_t>(std::max<size_t>((size_t)(h->n / 24), (size_t)1 << 22), (size_t)1 << 28);
     if (h->cap < want) { rc = ensure_capacity(h, want); if (rc) return rc; }
   }
@@ -580,7 +586,7 @@ extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8
   void *d = nullptr;
   HIP_TRY(h, hipMalloc(&d, (size_t)(n > 0 ? n : 1) + 16));
   const double ti1 = now_ms();
-  h->d_text = (const uint8_t *)d; h->own_d_text = true; h->h_text = text; h->n = n; h->stream = nullptr;
+  h->d_text = (const uint8_t *)d; h->own_d_text = true; h->h_text = text; h->n = n; h->stream = nullptr; h->host_only = false;
   // the stream crosses PCIe (≈0.3 s for 3 GB of pageable memory) while this thread builds the
   // pattern tables; raw streams with wildcards look at the stream on the device first, so they wait
   const bool overlap = n > ((int64_t)1 << 24) && !(!table && h->cfg.wildcards);
@@ -606,13 +612,22 @@ extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8
   return ensure_packed(h);
 }
 
+extern "C" int pm_init_host(pm_handle *h, const uint8_t *text, int64_t n, const uint8_t *table, int32_t table_len) {
+  if (!h || (!text && n > 0) || n < 0) return fail(h, PM_E_INVALID, "pm_init_host: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
+  h->d_text = nullptr; h->own_d_text = false; h->h_text = text; h->n = n; h->stream = nullptr;
+  h->host_only = true;
+  return init_common(h, table, table_len);
+}
+
 extern "C" int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *table, int32_t table_len,
                               void *hip_stream) {
   if (!h || (!d_text && n > 0) || n < 0) return fail(h, PM_E_INVALID, "pm_init_device: bad arguments");
   if (((uintptr_t)d_text) & 3) return fail(h, PM_E_INVALID, "pm_init_device: stream must be 4-byte aligned");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
-  h->d_text = (const uint8_t *)d_text; h->own_d_text = false; h->h_text = nullptr; h->n = n;
+  h->d_text = (const uint8_t *)d_text; h->own_d_text = false; h->h_text = nullptr; h->n = n; h->host_only = false;
   h->stream = (hipStream_t)hip_stream;
   const int rc = init_common(h, table, table_len);
   if (rc) return rc;
@@ -674,6 +689,7 @@ extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
 // ---- device stage ------------------------------------------------------------------------------
 extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end) {
   if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_scan_candidates: handle not initialised");
+  if (h->host_only) return fail(h, PM_E_INVALID, "pm_scan_candidates: this handle runs the host stage only (pm_init_host)");
   if (begin < 0 || end < begin) return fail(h, PM_E_INVALID, "pm_scan_candidates: bad range");
   if (end > h->n) end = h->n;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1392,6 +1408,7 @@ extern "C" int pm_finalize_device_owned(pm_handle *h, const void *d_cands, size_
 static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                                 const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out) {
   if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_finalize_device: handle not initialised");
+  if (h->host_only) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this handle runs the host stage only (use pm_finalize)");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const pm_hit *src = d_cands ? (const pm_hit *)d_cands : h->d_cands;
   if (!d_cands) n = h->last_count;

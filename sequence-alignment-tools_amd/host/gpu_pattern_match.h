@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pm_gpu.h"
+#include "pm_ranks.h"
 
 namespace pmgpu {
 
@@ -68,8 +69,12 @@ class GpuPatternMatch {
  public:
   // kernel: PM_KERNEL_AUTO / PM_KERNEL_BITPAR (-N 16) / PM_KERNEL_SEED (-N 17); the other
   // arguments are pick_pattern_index's (select.cc:19-30).  semantics forces a reference engine.
+  // group: the ranks of a position-sharded run (pm_ranks.h), or null / single.  With N ranks every
+  // rank scans its own shard of the stream on its own GPU and rank 0's find_patterns hands out the
+  // hits of the WHOLE stream; the other ranks' find_patterns returns nothing.
   GpuPatternMatch(int kernel, unsigned int k, char eos = '\n', bool wc = false, bool tn = false,
-                  bool indels = true, bool dna_mut = false, int semantics = PM_SEM_AUTO, int device = 0);
+                  bool indels = true, bool dna_mut = false, int semantics = PM_SEM_AUTO, int device = 0,
+                  RankGroup *group = nullptr);
   ~GpuPatternMatch();
   unsigned long add_pattern(std::string const &pat, unsigned long id = 0, int exact_start_bases = 0,
                             int exact_end_bases = 0);                         // pattern_match.h:116
@@ -79,10 +84,17 @@ class GpuPatternMatch {
   int selected_semantics() const;
   int selected_kernel() const;
   void chunk_bytes(int64_t c) { chunk_ = c; }
-  pm_handle *handle() const { return h_; }     // for the caller's per-hit re-alignment (pm_align_hits_text)
+  // for the caller's per-hit re-alignment (pm_align_hits_text): the handle that knows the whole stream
+  pm_handle *handle() const { return merge_ ? merge_ : h_; }
  private:
   [[noreturn]] void fatal(const char *what) const;
+  bool sharded_scan(CharacterProducer &cp, pattern_hit_vector &hits);
   pm_handle *h_ = nullptr;
+  pm_handle *merge_ = nullptr;                  // rank 0 of a sharded run: host-stage handle over the whole stream (pm_init_host)
+  pm_comm *comm_ = nullptr;                     // RCCL communicator when every rank has its own GPU
+  RankGroup *group_ = nullptr;
+  int64_t shard_ = 0, lo_ = 0, hi_ = 0, glo_ = 0, ghi_ = 0;   // this rank's slice of the stream and what it holds around it
+  bool sharded_done_ = false;
   std::vector<unsigned char> owned_;            // stream drained from a producer without c_str()
   int64_t n_ = 0;
   int64_t chunk_ = (int64_t)1 << 30;

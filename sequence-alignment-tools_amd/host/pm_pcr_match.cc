@@ -48,6 +48,7 @@ struct Options {
   fprintf(stderr,
           "Usage: pm_pcr_match [options]\n\n"
           "  -i <sequence-database>  database prepared by (pm_)compress_seq. Required.\n"
+          "  --ranks <n>             one process per GPU, the database sharded by position (default $PM_RANKS or 1)\n"
           "  -p <sequences> | -P <file> | -S <unists-file> | -F <fasta-file>   primer pairs (\"-\" = stdin)\n"
           "  -o <output-file>  -k <edits> | -K <mismatches>  -r  -a  -s -e -5 -3 <n|~n>  -u  -w  -W  -E <int>\n"
           "  -m <min amplicon>  -M <max amplicon, default 2000>  -d <deviation from UniSTS size>  -b\n"
@@ -231,7 +232,9 @@ struct Hit { int64_t key; unsigned long id; unsigned char value; };
 }  // namespace
 
 int main(int argc, char **argv) {
+  const int nranks = take_ranks_option(&argc, argv);                  // --ranks N: one process per GPU, the stream sharded by position
   Options opt = parse(argc, argv);
+  RankGroup ranks = RankGroup::launch(nranks);                      // returns in every rank process; forks before anything touches a GPU
   Phases ph; ph.on = opt.chatty;
   std::ofstream fout;
   if (!opt.out_path.empty()) fout.open(opt.out_path.c_str(), std::ios::out | std::ios::app | std::ios::ate);
@@ -323,7 +326,7 @@ int main(int argc, char **argv) {
   int kernel = PM_KERNEL_AUTO, semantics = PM_SEM_AUTO;
   if (opt.engine_choice == 16) kernel = PM_KERNEL_BITPAR;
   else if (opt.engine_choice != 17 && opt.engine_choice != 0) semantics = opt.engine_choice;
-  GpuPatternMatch pm(kernel, (unsigned)opt.max_edits, opt.eos, opt.iupac, opt.text_n_matches, opt.with_indels, false, semantics);
+  GpuPatternMatch pm(kernel, (unsigned)opt.max_edits, opt.eos, opt.iupac, opt.text_n_matches, opt.with_indels, false, semantics, 0, &ranks);
   size_t maxlen = 0;
   for (unsigned long i = 1; i <= N1; ++i) {
     pm.add_pattern(patarray[i], i, patconst[i].first, patconst[i].second);
@@ -331,6 +334,11 @@ int main(int argc, char **argv) {
   }
   BufferChars &ff = db.chars();
   pm.init(ff);
+  if (!ranks.single() && ranks.rank() != 0) {                        // this rank scans its shard, hands its records to rank 0 and is done
+    pattern_hit_vector none;
+    pm.find_patterns(ff, none, 1);
+    ranks.leave(0);
+  }
   ph.mark("Primer index built, stream resident on the GPU");
   double t_scan = 0, t_pair = 0;
   unsigned long nhits = 0, npairs = 0;

@@ -52,6 +52,7 @@ struct Options {
   fprintf(stderr,
           "Usage: pm_primer_match [options]\n\n"
           "  -i <sequence-database>  database prepared by (pm_)compress_seq. Required.\n"
+          "  --ranks <n>             one process per GPU, the database sharded by position (default $PM_RANKS or 1)\n"
           "  -p <sequences> | -P <file> | -F <fasta-file> | -S <unists-file>   primers (\"-\" = stdin)\n"
           "  -o <output-file>        append to file instead of standard out\n"
           "  -k <n> / -K <n>         edits / substitutions permitted (default 0)\n"
@@ -274,7 +275,9 @@ std::string with_gaps(const std::string &src, const std::string &ops, char gap_o
 }  // namespace
 
 int main(int argc, char **argv) {
+  const int nranks = take_ranks_option(&argc, argv);                  // --ranks N: one process per GPU, the stream sharded by position
   Options opt = parse(argc, argv);
+  RankGroup ranks = RankGroup::launch(nranks);                      // returns in every rank process; forks before anything touches a GPU
   Phases ph; ph.on = opt.chatty;
   std::ofstream fout;
   if (!opt.out_path.empty()) fout.open(opt.out_path.c_str(), std::ios::out | std::ios::app | std::ios::ate);
@@ -366,7 +369,7 @@ int main(int argc, char **argv) {
   if (opt.engine_choice == 16) kernel = PM_KERNEL_BITPAR;
   else if (opt.engine_choice == 17 || opt.engine_choice == 0) kernel = PM_KERNEL_AUTO;
   else semantics = opt.engine_choice;                            // reproduce that reference engine's hit set
-  GpuPatternMatch kt(kernel, (unsigned)opt.max_edits, opt.eos, opt.iupac, opt.text_n_matches, opt.with_indels, false, semantics);
+  GpuPatternMatch kt(kernel, (unsigned)opt.max_edits, opt.eos, opt.iupac, opt.text_n_matches, opt.with_indels, false, semantics, 0, &ranks);
   size_t maxlen = 0;
   for (unsigned long i = 1; i <= N1; ++i) {
     kt.add_pattern(patarray[i], i, patconst[i].first, patconst[i].second);
@@ -374,6 +377,11 @@ int main(int argc, char **argv) {
   }
   BufferChars &ff = db.chars();
   kt.init(ff);
+  if (!ranks.single() && ranks.rank() != 0) {                        // this rank scans its shard, hands its records to rank 0 and is done
+    pattern_hit_vector none;
+    kt.find_patterns(ff, none, 1);
+    ranks.leave(0);
+  }
   ph.mark("Primer index built, stream resident on the GPU");
   double t_scan = 0, t_report = 0;
   unsigned long nhits = 0;

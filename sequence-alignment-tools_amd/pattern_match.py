@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
     "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
-    "pm_final_hits_device", "pm_copy_records", "pm_pack_time",
+    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host",
+    "pm_comm_unique_id", "pm_comm_create", "pm_comm_gather", "pm_comm_destroy", "pm_comm_last_error",
 ]
 
 
@@ -69,7 +70,7 @@ def load_library():
         L.pm_destroy.argtypes = [C.c_void_p]
         for name in ABI_SYMBOLS:
             f = getattr(L, name)
-            if name not in ("pm_last_error", "pm_destroy"):
+            if name not in ("pm_last_error", "pm_destroy", "pm_comm_destroy", "pm_comm_last_error"):
                 f.restype = C.c_int
         L.pm_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
         L.pm_add_pattern.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_int32, C.c_int32]
