@@ -658,3 +658,13 @@ def test_large_hit_lists_come_back_sorted():
         assert got.size == n
         assert (got["end"] == c["end"][order]).all() and (got["pid"] == c["pid"][order]).all() and (got["k"] == c["k"][order]).all()
     pm.close()
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_golden_engine_hits_with_two_mi_chunks(path, monkeypatch):
+    """the chunk size large ranges get by default (2 Mi positions per workgroup), forced on the fixtures"""
+    monkeypatch.setenv("PM_SEED_CHUNK", "2097152")
+    c, codes, table, allp = load(path)
+    for name, e in c["engine"].items():
+        got = gpu_hits(codes, table, allp, SEL2SEM[e["sel"]], e["k"], e["indels"], sat_amd.KERNEL_AUTO)
+        assert got == [tuple(h) for h in e["hits"]], (c["name"], name)
