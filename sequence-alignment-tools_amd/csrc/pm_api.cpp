@@ -61,6 +61,10 @@ struct pm_handle {
   std::vector<SeedDevice> sd_more;    // further tiles when the pattern set is too large for one LDS filter
   std::vector<PairDevice> pair;       // -K 1 / -K 2 on 20..32 character patterns: the pair plan's tiles (pm_pair.hip) instead of sd
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
+  bool bases_flags = false;           // exact_bases -K on whole-pattern Hamming candidates with clean exact zones (pair plan): records are final
+  bool zoned = false;                 // some pattern has exact-base constraints
+  bool bases_edits = false;           // exact_bases -k on the seed family: the k-error automaton's candidates -> block seeds (pm_bases_seeds)
+  int64_t own_begin = 0, own_end = 0; //   the range the caller asked for (the candidates are scanned a little wider)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
   bool edits_dev = false;             // filter_bitvec / shift_and_inexact -k on the seed kernels: records deduplicated after the scan
   unsigned long long *d_seed_count = nullptr;   // edits: [0] unused, [1+t] seed records of tile t
@@ -317,9 +321,29 @@ static bool seed_eligible(pm_handle *h, std::string *why) {
     for (uint32_t id : h->inner_ids) if (id >= (1u << 22)) { *why = "the edit-distance seed plan packs pattern ids into 22 bits"; return false; }
     return true;
   }
+  if (h->cfg.k > 0 && h->cfg.indels && sem == PM_SEM_EXACT_BASES) {
+    // every exact_bases hit is a window within k edits of the whole pattern: the edit-distance seed plan
+    // finds those, pm_bases_seeds turns them into the reference's block seeds (pm_cluster.hip)
+    if (h->cfg.k > 2) { *why = "edit distance > 2 runs on the bit-parallel family"; return false; }
+    if (h->pats.size() >= ((size_t)1 << 22)) { *why = "the edit-distance seed plan packs pattern ids into 22 bits"; return false; }
+    for (const Pattern &p : h->pats) {
+      if (p.s.size() > 32 || p.s.size() < 20) { *why = "the edit-distance seed plan needs 20..32 character patterns"; return false; }
+      for (unsigned char ch : p.s) if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) { *why = "pattern with characters other than A,C,G,T"; return false; }
+    }
+    return true;
+  }
   if (h->cfg.k > 0 && h->cfg.indels && sem != PM_SEM_KEYWORD_TREE && sem != PM_SEM_SHIFT_AND) { *why = "edit-distance search (-k) runs on the bit-parallel family"; return false; }
-  if (sem == PM_SEM_EXACT_BASES) { *why = "exact_bases runs on the bit-parallel family"; return false; }
-  if (sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_EXACT_HALVES)
+  // substitution-only search of 20..32 character A,C,G,T patterns with k = 1, 2 runs on the pair plan
+  // (pm_pair.hip), whose exact verify knows the patterns' exact zones: a substitution there fails
+  // the reference's constrained verifies (pattern_alignment.cc:320-323, primer_alignment.cc:155)
+  bool pair_ok = !h->cfg.indels && (h->cfg.k == 1 || h->cfg.k == 2) && !h->pats.empty();
+  for (const Pattern &p : h->pats) {
+    pair_ok = pair_ok && p.s.size() >= 20 && p.s.size() <= 32;
+    for (unsigned char ch : p.s) pair_ok = pair_ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+  }
+  if (const char *env = getenv("PM_PAIR")) pair_ok = pair_ok && atoi(env) != 0;
+  if (sem == PM_SEM_EXACT_BASES && !pair_ok) { *why = "exact_bases runs on the bit-parallel family (the seed family takes it for -K 1 / -K 2 on 20..32 character patterns)"; return false; }
+  if ((sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_EXACT_HALVES) && !pair_ok)
     for (const Pattern &p : h->pats) if (p.esb || p.eeb) { *why = "exact-base constraints need the text-based verify of the bit-parallel family"; return false; }
   return true;
 }
@@ -350,7 +374,9 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   { void *lazy[] = {h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_fpat_len, h->d_fpat_id}; for (void *q : lazy) if (q) (void)hipFree(q); }
   h->d_dp_codes = nullptr; h->d_dp_esb = h->d_dp_eeb = nullptr; h->d_fpat_len = nullptr; h->d_fpat_id = nullptr;
   h->d_final = nullptr; h->n_final = 0;
-  h->seed_flags = false;
+  h->seed_flags = false; h->bases_flags = false; h->bases_edits = false;
+  h->zoned = false;
+  for (const Pattern &p : h->pats) h->zoned = h->zoned || p.esb || p.eeb;
   h->start_cached = false; h->start_cache.clear();
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
@@ -381,7 +407,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     std::vector<std::string> partners;
     std::vector<uint8_t> sides;
     const bool halves_mode = h->sem == PM_SEM_EXACT_HALVES && h->cfg.indels && h->cfg.k > 0;
-    const bool edits_mode = h->cfg.indels && h->cfg.k > 0 && (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT);
+    const bool edits_mode = h->cfg.indels && h->cfg.k > 0 && (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT || h->sem == PM_SEM_EXACT_BASES);
     if (halves_mode) {                            // halves as exact patterns (ids 2j+1, 2j+2), partner = other half
       sp = h->inner; sid = h->inner_ids; sk = 0;
       for (size_t i = 0; i + 1 < sp.size(); i += 2) {
@@ -390,6 +416,13 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       }
     } else if (h->sem == PM_SEM_EXACT_HALVES) {   // -K: whole patterns, distance <= k, halves decided by flags
       for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back((uint32_t)(i + 1)); }
+      sk = h->cfg.k;
+    } else if (h->sem == PM_SEM_EXACT_BASES) {
+      // -K: an occurrence of the mandated exact block whose remainder verifies (exact_bases.cc:92-121, the
+      // extension DP with indels off walks the diagonal) = a whole-pattern window within k substitutions,
+      // none of them in an exact zone; one hit per occurrence, no clustering: the records are final
+      // (-k: the records in between are the automaton's candidates of pattern i + 1, see pm_bases_seeds)
+      for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back(h->cfg.indels ? (uint32_t)(i + 1) : (uint32_t)h->pats[i].id); }
       sk = h->cfg.k;
     } else if (h->nrest) {
       for (size_t i = 0; i < h->inner.size(); ++i) if (!h->in_rest[i]) { sp.push_back(h->inner[i]); sid.push_back(h->inner_ids[i]); }
@@ -426,6 +459,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       }
       h->pair.emplace_back();
       HIP_TRY(h, pair_upload(pt, &h->pair.back(), h->stream));
+      h->pair.back().viol_level = h->sem == PM_SEM_FILTER_BITVEC ? 3 : 0;   // filter_bitvec chains every candidate; the others drop zone violations
       // the plan facts the rest of this file reads from h->sd (no device tables behind them)
       h->sd.k = sk; h->sd.Lw = 20; h->sd.pb = 5; h->sd.r = 4 - sk; h->sd.ncombos = pt.ncombos; h->sd.ascii = pt.ascii;
       h->sd.maxlen = std::max(h->sd.maxlen, pt.maxlen);
@@ -467,6 +501,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       h->sd.maxlen = mx;
       h->kern = PM_KERNEL_SEED;
       h->seed_flags = h->sem == PM_SEM_EXACT_HALVES && !halves_mode;
+      h->bases_flags = h->sem == PM_SEM_EXACT_BASES && !h->cfg.indels;
+      h->bases_edits = h->sem == PM_SEM_EXACT_BASES && h->cfg.indels;
       h->halves_dev = halves_mode;
       h->edits_dev = edits_mode;
       if (halves_mode) {
@@ -687,6 +723,8 @@ extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
 }
 
 // ---- device stage ------------------------------------------------------------------------------
+static int ensure_dp_tables(pm_handle *h);
+
 extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end) {
   if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_scan_candidates: handle not initialised");
   if (h->host_only) return fail(h, PM_E_INVALID, "pm_scan_candidates: this handle runs the host stage only (pm_init_host)");
@@ -695,6 +733,13 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  h->own_begin = begin; h->own_end = end;
+  if (h->bases_edits) { int rcd = ensure_dp_tables(h); if (rcd) return rcd; }
+  if (h->kern == PM_KERNEL_SEED && h->bases_edits) {                // a block seed comes from candidates up to maxlen + k away
+    const int64_t reach = (int64_t)h->sd.maxlen + 2 * h->cfg.k + 4;
+    begin = begin > reach ? begin - reach : 0;
+    end = std::min<int64_t>(h->n, end + reach);
+  }
   if (h->kern == PM_KERNEL_SEED && h->edits_dev)
   {
     // per pattern tile: scan kernel -> seed records in d_ext, verify kernel -> candidates in d_cands
@@ -712,6 +757,10 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, (1 + 256) * sizeof(unsigned long long), h->stream));
     for (int t = 0; t < ntiles; ++t) {
       EditStage es; es.d_seeds = h->d_seeds; es.d_seed_count = h->d_seed_count + 1 + t; es.seed_cap = h->seed_cap; es.tile = t;
+      if (h->bases_edits) {
+        es.bases = true; es.b_codes = h->d_dp_codes; es.b_len = h->d_fpat_len; es.b_esb = h->d_dp_esb; es.b_eeb = h->d_dp_eeb;
+        es.own_lo = h->own_begin; es.own_hi = h->own_end;
+      }
       const SeedDevice &d = t == 0 ? h->sd : h->sd_more[t - 1];
       HIP_TRY(h, seed_launch(d, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 ? &h->geo : nullptr, &es));
     }
@@ -868,6 +917,39 @@ static int stream_start_candidates(pm_handle *h) {
   return PM_OK;
 }
 
+// per pattern (index = position in the pattern list): 32 stream codes, length, exact zones -- what the
+// device-side DPs (pm_cluster_dp) and pm_bases_seeds read
+static int ensure_dp_tables(pm_handle *h) {
+  const size_t np = h->pats.size();
+  if (!h->d_dp_codes) {
+    std::vector<uint8_t> codes(np * 32, 0);
+    std::vector<int32_t> es(np), ee(np);
+    for (size_t i = 0; i < np; ++i) {
+      for (size_t q = 0; q < h->pats[i].s.size() && q < 32; ++q) codes[i * 32 + q] = (uint8_t)h->alpha.nch[(unsigned char)h->pats[i].s[q]];
+      es[i] = h->pats[i].esb; ee[i] = h->pats[i].eeb;
+    }
+    HIP_TRY(h, hipMalloc((void **)&h->d_dp_codes, codes.size() ? codes.size() : 32));
+    HIP_TRY(h, hipMalloc((void **)&h->d_dp_esb, np ? np * 4 : 4));
+    HIP_TRY(h, hipMalloc((void **)&h->d_dp_eeb, np ? np * 4 : 4));
+    if (np) {
+      HIP_TRY(h, hipMemcpy(h->d_dp_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_dp_esb, es.data(), np * 4, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_dp_eeb, ee.data(), np * 4, hipMemcpyHostToDevice));
+    }
+  }
+  if (!h->d_fpat_len) {
+    std::vector<uint8_t> pl(np); std::vector<uint32_t> pi(np);
+    for (size_t i = 0; i < np; ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
+    HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));
+    HIP_TRY(h, hipMalloc((void **)&h->d_fpat_id, pi.size() ? pi.size() * 4 : 4));
+    if (!pl.empty()) {
+      HIP_TRY(h, hipMemcpy(h->d_fpat_len, pl.data(), pl.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  return PM_OK;
+}
+
 extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   if (!h || !h->scan_pending) return fail(h, PM_E_INVALID, "pm_scan_wait: no scan in flight");
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -917,7 +999,7 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     }
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
-    if (h->scan_begin == 0) {
+    if (h->scan_begin == 0 && !h->bases_edits) {                    // (exact_bases: the records are block seeds, not automaton ends)
       std::vector<pm_hit> extra;
       int rc = edits_start_candidates(h, &extra);
       if (rc) return rc;
@@ -1347,7 +1429,10 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
       rc = h->seed_flags ? finalize_halves_flags(h, cands, n, scanned_to, last, outv)
          : h->halves_dev ? finalize_extended(h, cands, n, outv) : finalize_seeds(h, cands, n, true, outv);
       break;
-    case PM_SEM_EXACT_BASES: rc = finalize_seeds(h, cands, n, false, outv); break;
+    case PM_SEM_EXACT_BASES:
+      if (h->bases_flags) outv.insert(outv.end(), cands, cands + n);   // seed family: the records are the hits
+      else rc = finalize_seeds(h, cands, n, false, outv);
+      break;
     default: return fail(h, PM_E_INVALID, "finalize: bad semantics");
   }
   return rc;
@@ -1381,7 +1466,8 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
 // (pm_cluster.hip), no stream text needed
 static bool device_cluster_plain(const pm_handle *h) {
   if (!(h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.indels && h->cfg.k <= 3 && h->pats.size() < ((size_t)1 << 22))) return false;
-  for (const Pattern &p : h->pats) if (p.esb || p.eeb) return false;
+  // with exact-base constraints only on the pair plan, whose records mark zone violations (level 3, k <= 2)
+  if (h->zoned) return h->kern == PM_KERNEL_SEED && !h->pair.empty() && h->nrest == 0 && h->cfg.k <= 2;
   return true;
 }
 
@@ -1418,7 +1504,8 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   const bool keep = out == nullptr;
   h->d_final = nullptr; h->n_final = 0;
   if (keep && (flags & PM_FINALIZE_SORTED)) return fail(h, PM_E_INVALID, "pm_finalize_device: PM_FINALIZE_SORTED needs a host buffer");
-  const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT;
+  const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT ||
+                           (h->sem == PM_SEM_EXACT_BASES && h->bases_flags);
   // edits on the seed family (A,C,G,T patterns of <= 32 characters): clusters and their DPs on the device
   const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && h->pats.size() < ((size_t)1 << 22);
   const bool cluster = cluster_dp || device_cluster_plain(h);
@@ -1494,23 +1581,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
       HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
     }
   }
-  if (cluster_dp && !h->d_dp_codes) {
-    const size_t np = h->pats.size();
-    std::vector<uint8_t> codes(np * 32, 0);
-    std::vector<int32_t> es(np), ee(np);
-    for (size_t i = 0; i < np; ++i) {
-      for (size_t q = 0; q < h->pats[i].s.size() && q < 32; ++q) codes[i * 32 + q] = (uint8_t)h->alpha.nch[(unsigned char)h->pats[i].s[q]];
-      es[i] = h->pats[i].esb; ee[i] = h->pats[i].eeb;
-    }
-    HIP_TRY(h, hipMalloc((void **)&h->d_dp_codes, codes.size() ? codes.size() : 32));
-    HIP_TRY(h, hipMalloc((void **)&h->d_dp_esb, np ? np * 4 : 4));
-    HIP_TRY(h, hipMalloc((void **)&h->d_dp_eeb, np ? np * 4 : 4));
-    if (np) {
-      HIP_TRY(h, hipMemcpy(h->d_dp_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
-      HIP_TRY(h, hipMemcpy(h->d_dp_esb, es.data(), np * 4, hipMemcpyHostToDevice));
-      HIP_TRY(h, hipMemcpy(h->d_dp_eeb, ee.data(), np * 4, hipMemcpyHostToDevice));
-    }
-  }
+  if (cluster_dp) { int rcd = ensure_dp_tables(h); if (rcd) return rcd; }
   // candidates an earlier range left undecided (clusters that could still grow) join this batch on
   // the device: their chains continue here
   std::vector<pm_hit> hostpart;
@@ -1532,7 +1603,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
                                  h->d_dp_esb, h->d_dp_eeb, h->d_fpat_id, own, h->d_keys, h->d_keys_alt, h->d_ctemp, h->ctemp_bytes,
                                  h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
   else
-  HIP_TRY(h, cluster_device(src, n, h->d_carry, ncarry, h->cfg.k, scanned_to, last, h->d_fpat_len, h->d_fpat_id, own, h->d_keys, h->d_keys_alt,
+  HIP_TRY(h, cluster_device(src, n, h->d_carry, ncarry, h->cfg.k, scanned_to, last, h->zoned ? 3 : -1, h->d_fpat_len, h->d_fpat_id, own, h->d_keys, h->d_keys_alt,
                             h->d_ctemp, h->ctemp_bytes, h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
   h->h_fcounts[2] = 0;
   HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, (n ? 3 : 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));

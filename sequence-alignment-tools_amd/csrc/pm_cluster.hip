@@ -52,7 +52,7 @@ __device__ __forceinline__ bool hit_owned(const OwnedRange &own, int64_t end) {
   return !own.on || (end > own.own_lo && end <= own.own_hi);
 }
 
-__global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64_t scanned_to, int last,
+__global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64_t scanned_to, int last, int invalid_level,
                                   const uint8_t *pat_len, const uint32_t *pat_id, OwnedRange own,
                                   pm_hit *out, unsigned long long *out_count,
                                   pm_hit *left, unsigned long long *left_count) {
@@ -87,7 +87,9 @@ __global__ void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64
       h.aux[0] = h.aux[1] = h.aux[2] = 0;
       left[o + (t - i)] = h;
     }
-  } else if (hit_owned(own, best_end)) {
+  } else if (best != invalid_level && hit_owned(own, best_end)) {
+    // (invalid_level: candidates whose substitutions touch an exact zone take part in the chain but
+    // cannot be its hit -- the reference's constrained verify fails on them, pattern_alignment.cc:320-323)
     const unsigned long long o = wave_reserve_slot(out_count);
     pm_hit h;
     h.pid = pat_id[pid - 1]; h.end = best_end; h.k = (uint8_t)best; h.aux[0] = h.aux[1] = h.aux[2] = 0;
@@ -423,7 +425,7 @@ size_t cluster_temp_bytes(size_t n) {
   return bytes;
 }
 
-hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, int64_t scanned_to, bool last,
+hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, int64_t scanned_to, bool last, int invalid_level,
                           const uint8_t *d_pat_len, const uint32_t *d_pat_id, const OwnedRange &own,
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st) {
@@ -436,7 +438,7 @@ hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, si
   if (n2) hipLaunchKernelGGL(pm_cluster_pack, dim3((unsigned)((n2 + threads - 1) / threads)), dim3(threads), 0, st, d_in2, n2, d_keys + n1);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n, 0, 64, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(pm_cluster_reduce, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, 2 * k + 1, scanned_to, last ? 1 : 0,
+  hipLaunchKernelGGL(pm_cluster_reduce, dim3(blocks), dim3(threads), 0, st, d_keys_alt, n, 2 * k + 1, scanned_to, last ? 1 : 0, invalid_level,
                      d_pat_len, d_pat_id, own, d_out, d_counts, d_left, d_counts + 1);
   return hipGetLastError();
 }

@@ -86,7 +86,8 @@ hipError_t gather_windows(const uint8_t *d_text, int64_t n, const int64_t *d_sta
 struct OwnedRange { int64_t own_lo, own_hi, guard_lo, guard_hi; int on; };
 
 size_t cluster_temp_bytes(size_t n);
-hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, int64_t scanned_to, bool last,
+// invalid_level: records with this level chain like any other but are never a chain's hit (-1: none)
+hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, size_t n2, int k, int64_t scanned_to, bool last, int invalid_level,
                           const uint8_t *d_pat_len, const uint32_t *d_pat_id, const OwnedRange &own,
                           uint64_t *d_keys, uint64_t *d_keys_alt, void *d_temp, size_t temp_bytes,
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);

@@ -42,6 +42,7 @@ struct PairTables {                                 // one pattern tile
   std::vector<uint8_t> pat_len;
   std::vector<uint32_t> pat_id;
   std::vector<uint8_t> pat_codes;                   // 32 stream codes per pattern
+  std::vector<uint32_t> pat_zone;                   // bit i: pattern character i lies in an exact zone
 };
 
 struct PairDevice {
@@ -54,6 +55,8 @@ struct PairDevice {
   uint32_t *image = nullptr, *entries = nullptr, *first_pat = nullptr, *order = nullptr, *pat_id = nullptr;
   uint64_t *pat40 = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr;
+  uint32_t *pat_zone = nullptr;
+  int viol_level = 0;                                 // see PairArgs::viol_level (set by the caller after pair_upload)
 };
 
 // "" or why the plan does not take this pattern set

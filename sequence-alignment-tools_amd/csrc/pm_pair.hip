@@ -84,6 +84,9 @@ struct PairArgs {
   const uint8_t *pat_len;
   const uint32_t *pat_id;
   const uint8_t *pat_codes;
+  const uint32_t *pat_zone;             // per pattern: bit i = character i lies in an exact zone (exact_start_bases / exact_end_bases)
+  int viol_level;                       // a mismatch inside an exact zone: > 0 = report the candidate with this level (filter_bitvec
+                                        // chains every candidate and verifies the chain), 0 = not a candidate (exact_halves, exact_bases)
   pm_hit *out;
   unsigned long long *counter;
   unsigned long long cap;
@@ -165,8 +168,14 @@ __device__ __forceinline__ void pair_verify(const PairArgs &a, int combo, int64_
   const uint32_t lenmask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
   mism &= lenmask;
   if (a.eos_code >= 0 && (eos & lenmask)) return;     // EOS inside the window: never a candidate
-  const int ham = __popc(mism);                       // N (or any other code) = mismatch
+  int ham = __popc(mism);                             // N (or any other code) = mismatch
   if (ham > a.k) return;
+  // exact-base constraints (pattern_alignment.cc:320-323: a substitution inside an exact zone is a
+  // constraint violation, the verify fails)
+  if (mism & a.pat_zone[pi]) {
+    if (a.viol_level <= 0) return;
+    ham = a.viol_level;
+  }
   const uint32_t tail = mism >> (L - 20);             // the 20 bases the plan looks at
   uint32_t dirty = 0;
 #pragma unroll
@@ -558,7 +567,7 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
   const size_t np = pats.size();
   if (np == 0) return "no patterns";
   if (np >= ((size_t)1 << 30)) return "too many patterns";
-  t.pat40.resize(np); t.pat_len.resize(np); t.pat_id.resize(np); t.pat_codes.assign(np * 32, 0);
+  t.pat40.resize(np); t.pat_len.resize(np); t.pat_id.resize(np); t.pat_codes.assign(np * 32, 0); t.pat_zone.assign(np, 0);
   for (size_t j = 0; j < np; ++j) {
     const std::string &s = pats[j].s;
     const int L = (int)s.size();
@@ -574,6 +583,12 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
       t.pat_codes[j * 32 + i] = (uint8_t)alpha.nch[(unsigned char)s[i]];
     }
     t.pat40[j] = w; t.pat_len[j] = (uint8_t)L; t.pat_id[j] = ids[j];
+    {
+      const int es = std::max(0, std::min(L, pats[j].esb)), ee = std::max(0, std::min(L, pats[j].eeb));
+      uint32_t z = 0;
+      for (int i = 0; i < L; ++i) if (i < es || i >= L - ee) z |= 1u << i;
+      t.pat_zone[j] = z;
+    }
     t.maxlen = std::max(t.maxlen, L);
   }
   // field pairs in the order that decides who reports a pair found several times
@@ -670,6 +685,7 @@ hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
   if ((e = up(t.pat_len.data(), t.pat_len.size(), (void **)&d->pat_len)) != hipSuccess) return e;
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
   if ((e = up(t.pat_codes.data(), t.pat_codes.size(), (void **)&d->pat_codes)) != hipSuccess) return e;
+  if ((e = up(t.pat_zone.data(), t.pat_zone.size() * 4, (void **)&d->pat_zone)) != hipSuccess) return e;
   // the kernel addresses the bitmap from LDS address 0: it must have no static LDS in front of the dynamic block
   hipFuncAttributes fa;
   if ((e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(pm_pair_scan))) != hipSuccess) return e;
@@ -679,7 +695,7 @@ hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
 }
 
 void pair_free(PairDevice *d) {
-  void *ptrs[] = {d->image, d->entries, d->direct, d->first_pat, d->order, d->pat_id, d->pat40, d->pat_len, d->pat_codes};
+  void *ptrs[] = {d->image, d->entries, d->direct, d->first_pat, d->order, d->pat_id, d->pat40, d->pat_len, d->pat_codes, d->pat_zone};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = PairDevice();
 }
@@ -724,7 +740,7 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   }
   a.image = d.image; a.direct = d.direct; a.entries = reinterpret_cast<const uint2 *>(d.entries); a.first_pat = d.first_pat; a.order = d.order;
   a.np = (uint32_t)d.np;
-  a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id; a.pat_codes = d.pat_codes;
+  a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id; a.pat_codes = d.pat_codes; a.pat_zone = d.pat_zone; a.viol_level = d.viol_level;
   a.out = d_out; a.counter = d_counter; a.cap = cap;
   if (!d_susp || !d_susp_count) return hipErrorInvalidValue;
   a.susp = reinterpret_cast<uint4 *>(d_susp); a.susp_count = d_susp_count; a.susp_cap = susp_cap;   // *d_susp_count zeroed by the caller (stream order)

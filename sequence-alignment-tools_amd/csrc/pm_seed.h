@@ -73,6 +73,11 @@ struct EditStage {
   unsigned long long *d_seed_count = nullptr;     // zeroed by the caller before every launch
   uint64_t seed_cap = 0;
   int tile = 0;
+  // exact_bases -k (see pm_bases_verify): per pattern of the whole list (seed-plan pattern ids are 1-based indices into it)
+  bool bases = false;
+  const uint8_t *b_codes = nullptr, *b_len = nullptr;             // 32 stream codes per pattern, length
+  const int32_t *b_esb = nullptr, *b_eeb = nullptr;
+  int64_t own_lo = 0, own_hi = 0;                                   // seed records with own_lo < end <= own_hi are reported
 };
 // 2-bit form of the stream for the scan kernels' first stage: d_packed holds (n + 15) / 16 dwords
 hipError_t pack_stream(const uint8_t *d_text, int64_t n, bool ascii, uint32_t *d_packed, int64_t npacked, hipStream_t st);

@@ -973,6 +973,82 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
   if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
 }
 
+// exact_bases with edits on the seed family.  exact_bases (exact_bases.cc:69-129) reports, for every
+// exact occurrence of a pattern's mandated block (its first esb or last eeb characters), the banded
+// extension of the remainder when it succeeds (primer_alignment.cc:568-728).  Such a hit is a window
+// within k edits of the whole pattern, which the edit-distance plan's seeds (three clean pieces under a
+// displacement pattern + the q-gram test) cannot miss -- while exact block seeds (4^8 keys for an
+// 8-base block: every position is a seed of some pattern) would flood the second stage.  The k-error
+// automaton itself is NOT the right test here: behind an end-of-sequence character it cannot delete a
+// pattern's first characters (rows cleared), the extension DP can.  So: for a seed (pattern, p) the
+// pattern ends within k of p+1; try the block at every start that allows, and emit the reference's seed
+// record (end of the block occurrence) for the host's extension DPs; duplicates leave with the dedup.
+struct BasesArgs {
+  const uint8_t *codes, *len;
+  const int32_t *esb, *eeb;
+  int64_t own_lo, own_hi;
+};
+
+__global__ __launch_bounds__(256) void pm_bases_verify(EditVerifyArgs v, BasesArgs b) {
+  const SeedArgs &a = v.a;
+  unsigned long long n = *v.nseeds;
+  if (n > v.seed_cap) n = v.seed_cap;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long rounds = (n + stride - 1) / stride;     // same trip count for every lane: ballots stay whole-wave
+  const int lane = threadIdx.x & 63;
+  const int k = a.edits;
+  unsigned long long ob_next = 0;
+  int ob_left = 0;
+  for (unsigned long long it = 0; it < rounds; ++it) {
+    const unsigned long long i = it * stride + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    int64_t p = 0;
+    uint32_t pid = 0;
+    int L = 0, blk = 0;
+    bool prefix = true;
+    const uint8_t *pc = nullptr;
+    if (i < n) {
+      const uint64_t sd = v.seeds[i];
+      if (sd != ~0ull) {
+        live = true;
+        p = (int64_t)(sd & 0xffffffffffull);
+        pid = a.pat_id[(uint32_t)(sd >> 40)];                        // 1-based index into the whole pattern list
+        L = b.len[pid - 1];
+        const int es = b.esb[pid - 1], ee = b.eeb[pid - 1];
+        prefix = es >= ee;                                           // exact_bases.cc:139-150: the larger block decides
+        blk = prefix ? es : ee;
+        pc = b.codes + (size_t)(pid - 1) * 32 + (prefix ? 0 : L - blk);
+      }
+    }
+    // pattern end e in p+1-k .. p+1+k; prefix block: the pattern starts at e - L - d, |d| <= k
+    for (int t = -2 * k; t <= 2 * k; ++t) {
+      bool ok = live && blk > 0 && (prefix || (t >= -k && t <= k));
+      const int64_t b0 = prefix ? p + 1 - L + t : p + 1 + t - blk;
+      ok = ok && b0 >= 0 && b0 + blk <= a.n;
+      const int64_t send = b0 + blk;
+      ok = ok && send > b.own_lo && send <= b.own_hi;
+      for (int q = 0; q < blk && ok; ++q) ok = a.text[b0 + q] == pc[q];
+      const unsigned long long bal = __ballot(ok);
+      if (bal == 0) continue;
+      const int c = __popcll(bal);
+      if (c > ob_left) {
+        if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+        ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                  __builtin_amdgcn_readfirstlane((uint32_t)base);
+        ob_left = SEED_OUT_BLOCK;
+      }
+      if (ok) {
+        const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        if (slot < a.cap) { pm_hit hh; hh.end = send; hh.pid = pid; hh.k = 0; hh.aux[0] = hh.aux[1] = hh.aux[2] = 0; a.out[slot] = hh; }
+      }
+      ob_next += c; ob_left -= c;
+    }
+  }
+  if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+}
+
 // The stream at 2 bits per base, made once per pm_init (a re-encoding of the database like the
 // reference's compress_seq output formats, not part of a scan): dword i = bases 16i .. 16i+15,
 // base j in bits 2j, codes as pack4 derives them (A,C,G,T exact; any other byte aliases to one of
@@ -1369,6 +1445,11 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
     EditVerifyArgs v;
     v.a = a;
     v.seeds = es->d_seeds; v.nseeds = es->d_seed_count; v.seed_cap = es->seed_cap;
+    if (es->bases) {
+      BasesArgs b;
+      b.codes = es->b_codes; b.len = es->b_len; b.esb = es->b_esb; b.eeb = es->b_eeb; b.own_lo = es->own_lo; b.own_hi = es->own_hi;
+      hipLaunchKernelGGL(pm_bases_verify, dim3(256 * 16), dim3(256), 0, st, v, b);
+    } else
     hipLaunchKernelGGL(pm_edits_verify, dim3(256 * 16), dim3(256), 0, st, v);
   }
   else if (d.halves) hipLaunchKernelGGL((pm_seed_scan<0, 0, true>), grid, block, SEED_LDS_BYTES, st, a);

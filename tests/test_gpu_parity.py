@@ -668,3 +668,43 @@ def test_golden_engine_hits_with_two_mi_chunks(path, monkeypatch):
     for name, e in c["engine"].items():
         got = gpu_hits(codes, table, allp, SEL2SEM[e["sel"]], e["k"], e["indels"], sat_amd.KERNEL_AUTO)
         assert got == [tuple(h) for h in e["hits"]], (c["name"], name)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_exact_zones_on_the_seed_family(seed):
+    """-s/-e/-5/-3 style exact zones with substitution-only search (-K) on 20..32 character primers stay
+    on the seed family (pair plan): its exact verify knows the zones -- a substitution inside one fails
+    the reference's constrained verifies (pattern_alignment.cc:320-323, primer_alignment.cc:155) --
+    for filter_bitvec (zone violations still chain, filter_bitvec.cc:103-116), exact_halves and
+    exact_bases (exact_bases.cc:92-121).  Edits (-k): filter_bitvec's cluster DPs and exact_halves'
+    extension DPs take the zones on the GPU as before."""
+    rng = np.random.default_rng(1200 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(600, 2500)), n_runs=2, repeats=(seed % 2 == 0))
+    L = int(rng.integers(20, 27))
+    pats = synth.make_patterns(rng, ents, int(rng.integers(20, 80)), length=L, planted=0.85)
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    text = O.Text(codes, table)
+    for esb, eeb in [(8, 0), (0, 7), (6, 9), (3, 0), (0, 12)]:
+        E, F = [esb] * len(allp), [eeb] * len(allp)
+        for sem, k, ind in [(sat_amd.SEM_AUTO, 1, False), (sat_amd.SEM_AUTO, 2, False), (sat_amd.SEM_FILTER_BITVEC, 2, False),
+                            (sat_amd.SEM_FILTER_BITVEC, 1, False), (sat_amd.SEM_EXACT_HALVES, 2, False), (sat_amd.SEM_EXACT_HALVES, 1, False),
+                            (sat_amd.SEM_FILTER_BITVEC, 2, True), (sat_amd.SEM_EXACT_HALVES, 1, True),
+                            (sat_amd.SEM_AUTO, 2, True), (sat_amd.SEM_AUTO, 1, True), (sat_amd.SEM_EXACT_BASES, 1, True), (sat_amd.SEM_EXACT_BASES, 2, True),
+                            (sat_amd.SEM_EXACT_BASES, 2, False)]:
+            if sem == sat_amd.SEM_EXACT_BASES and max(esb, eeb) < 6:
+                continue                                              # select.cc:131: exact_bases needs >= 6 mandated bases
+            eng = {sat_amd.SEM_AUTO: O.pick_engine(text, allp, k, ind, E, F), sat_amd.SEM_FILTER_BITVEC: 5, sat_amd.SEM_EXACT_HALVES: 12,
+                   sat_amd.SEM_EXACT_BASES: 8}[sem]
+            want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=ind, esb=E, eeb=F))
+            pm = sat_amd.PatternMatch(k=k, indels=ind, semantics=sem)
+            for i, p in enumerate(allp):
+                pm.add_pattern(p, i + 1, E[i], F[i])
+            pm.init(codes, table)
+            assert pm.selected()[1] == sat_amd.KERNEL_SEED, (esb, eeb, sem, k, ind, pm.describe())
+            got = sat_amd.sorted_tuples(pm.find_all())
+            assert got == want, (seed, esb, eeb, sem, k, ind, eng, len(want), len(got))
+            # resumable: small consecutive ranges (seeds and chains across range edges) give the same hits
+            assert sat_amd.sorted_tuples(pm.find_all(chunk=193)) == want, (seed, esb, eeb, sem, k, ind, "chunked")
+            pm.close()
