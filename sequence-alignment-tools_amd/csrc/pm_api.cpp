@@ -63,6 +63,7 @@ struct pm_handle {
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool bases_flags = false;           // exact_bases -K on whole-pattern Hamming candidates with clean exact zones (pair plan): records are final
   bool zoned = false;                 // some pattern has exact-base constraints
+  bool wild_seed = false;             // -w/-W on the seed family: primers with <= 2 ambiguity letters expanded into their concrete variants
   bool bases_edits = false;           // exact_bases -k on the seed family: the k-error automaton's candidates -> block seeds (pm_bases_seeds)
   int64_t own_begin = 0, own_end = 0; //   the range the caller asked for (the candidates are scanned a little wider)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
@@ -299,11 +300,49 @@ static int resolve(pm_handle *h) {
   return PM_OK;
 }
 
+// -w / -W on the seed family.  The seed kernels compare A,C,G,T exactly, so an ambiguity letter of a
+// primer is expanded at table build: the primer becomes its concrete variants (same id), and the
+// smallest distance over the variants is the wildcard distance (shift_and.cc:108-117: a pattern
+// character accepts every stream letter of its IUPAC compatibility set).  That is only the whole story
+// while the STREAM holds nothing but A,C,G,T (and N without -W): a stream letter R would match a
+// primer's A under -w.
+static std::string acgt_of(unsigned char ch) {                      // the A,C,G,T a pattern character accepts under -w
+  std::string r;
+  const char *set = iupac_compatible_set(ch);
+  if (!set) return r;
+  for (const char *q = set; *q; ++q) if (*q == 'A' || *q == 'C' || *q == 'G' || *q == 'T') r.push_back(*q);
+  return r;
+}
+static bool stream_letters_plain(const pm_handle *h) {
+  for (int c = 0; c < h->alpha.size && c < 256; ++c) {
+    if (!h->alpha.present[c] || c == h->eos_code) continue;
+    const unsigned char l = h->alpha.ch[c];
+    if (l == 'A' || l == 'C' || l == 'G' || l == 'T') continue;
+    if (l == 'N' && !h->cfg.text_n) continue;                       // a text N matches nothing without -W
+    return false;
+  }
+  return true;
+}
+// concrete variants of a primer (at most `cap`; empty + false when there would be more)
+static bool expand_iupac(const std::string &p, size_t cap, std::vector<std::string> *out) {
+  out->assign(1, std::string());
+  for (unsigned char ch : p) {
+    const std::string alts = acgt_of(ch);
+    if (alts.empty()) { out->clear(); return true; }                // accepts no base at all: the primer cannot match
+    if (out->size() * alts.size() > cap) { out->clear(); return false; }
+    std::vector<std::string> next;
+    next.reserve(out->size() * alts.size());
+    for (const std::string &pre : *out) for (char a : alts) next.push_back(pre + a);
+    out->swap(next);
+  }
+  return true;
+}
+
 // Inner pattern set of the seed family: Hamming candidates of the WHOLE patterns; the wrappers'
 // rules are then applied to (end, pattern, distance, clean-half flags) records on the host.
 static bool seed_eligible(pm_handle *h, std::string *why) {
   const int sem = h->sem;
-  if (h->cfg.wildcards) { *why = "IUPAC wildcards run on the bit-parallel family"; return false; }
+  if (h->cfg.wildcards && !h->wild_seed) { *why = "IUPAC wildcards run on the bit-parallel family (the seed family takes them on A,C,G,T streams for the exact engines and filter_bitvec)"; return false; }
   if (h->cfg.k > 0 && h->cfg.indels && sem == PM_SEM_EXACT_HALVES) {
     // exact_halves with edits: exact seeds of the halves + partner prefilter on the GPU, DP on the host
     if (h->cfg.k > 2) { *why = "exact_halves -k > 2 runs on the bit-parallel family"; return false; }
@@ -387,12 +426,16 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->in_rest.assign(h->inner.size(), 0);
   h->nrest = 0;
   const bool edits_plan = h->cfg.indels && h->cfg.k > 0 && (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT);
-  if (want_seed && !h->cfg.wildcards && h->kern == PM_KERNEL_AUTO &&
+  h->wild_seed = h->cfg.wildcards && want_seed && h->kern == PM_KERNEL_AUTO && stream_letters_plain(h) &&
+                 (h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_FILTER_BITVEC);
+  if (want_seed && (!h->cfg.wildcards || h->wild_seed) && h->kern == PM_KERNEL_AUTO &&
       (h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT || h->sem == PM_SEM_FILTER_BITVEC)) {
+    std::vector<std::string> variants;
     for (size_t i = 0; i < h->inner.size(); ++i) {
       const std::string &ps = h->inner[i].s;
       bool ok = ps.size() <= 32 && ps.size() >= (edits_plan ? 20u : 10u);
-      for (unsigned char ch : ps) ok = ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+      if (h->wild_seed) ok = ok && expand_iupac(ps, 16, &variants);   // up to two ambiguity letters (16 variants)
+      else for (unsigned char ch : ps) ok = ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
       if (!ok) { h->in_rest[i] = 1; ++h->nrest; }
     }
     if (h->nrest == h->inner.size()) { std::fill(h->in_rest.begin(), h->in_rest.end(), 0); h->nrest = 0; }   // nothing for the seed family: one engine
@@ -424,6 +467,14 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       // (-k: the records in between are the automaton's candidates of pattern i + 1, see pm_bases_seeds)
       for (size_t i = 0; i < h->pats.size(); ++i) { sp.push_back(h->pats[i]); sid.push_back(h->cfg.indels ? (uint32_t)(i + 1) : (uint32_t)h->pats[i].id); }
       sk = h->cfg.k;
+    } else if (h->wild_seed) {                    // every concrete variant of a primer is a seed-family pattern with the primer's id
+      std::vector<std::string> variants;
+      for (size_t i = 0; i < h->inner.size(); ++i) {
+        if (h->in_rest[i]) continue;
+        expand_iupac(h->inner[i].s, 16, &variants);
+        for (const std::string &v : variants) { Pattern q = h->inner[i]; q.s = v; sp.push_back(q); sid.push_back(h->inner_ids[i]); }
+      }
+      if (sp.empty()) { sp.push_back(Pattern{std::string(edits_mode ? 20 : 10, 'A'), 0, 0, 0}); sid.push_back(0); why = "no primer the seed family could take"; }
     } else if (h->nrest) {
       for (size_t i = 0; i < h->inner.size(); ++i) if (!h->in_rest[i]) { sp.push_back(h->inner[i]); sid.push_back(h->inner_ids[i]); }
     } else { sp = h->inner; sid = h->inner_ids; }
@@ -492,7 +543,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
         std::vector<Pattern> rp; std::vector<uint32_t> rid;
         for (size_t i = 0; i < h->inner.size(); ++i) if (h->in_rest[i]) { rp.push_back(h->inner[i]); rid.push_back(h->inner_ids[i]); }
         BitparTables tabs;
-        std::string msg = bitpar_build(rp, rid, h->alpha, h->scan_k, h->eos_code, &tabs, false, false);
+        std::string msg = bitpar_build(rp, rid, h->alpha, h->scan_k, h->eos_code, &tabs, h->cfg.wildcards != 0, h->cfg.text_n != 0);
         if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine (residue): " + msg);
         HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
       }
@@ -854,7 +905,8 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
     uint64_t M[4] = {0, 0, 0, 0};                       // positions of A, C, G, T (the only pattern characters of the seed family)
     int code[4];
     for (int q = 0; q < 4; ++q) code[q] = h->alpha.nch[(unsigned char)"ACGT"[q]];
-    for (int i = 0; i < L; ++i) for (int q = 0; q < 4; ++q) if (s[i] == "ACGT"[q]) M[q] |= 1ull << i;
+    for (int i = 0; i < L; ++i) for (int q = 0; q < 4; ++q)
+      if (h->wild_seed ? acgt_of((unsigned char)s[i]).find("ACGT"[q]) != std::string::npos : s[i] == "ACGT"[q]) M[q] |= 1ull << i;
     for (int64_t t = 0; t < T; ++t) {
       const int c = head[t];
       if (c == h->eos_code) { R[0] = R[1] = R[2] = 0; continue; }
@@ -898,6 +950,7 @@ static int stream_start_candidates(pm_handle *h) {
       bool dead = false;
       for (int i = 0; i < e && !dead; ++i) {
         if ((int)head[i] == h->eos_code) dead = true;                // EOS clears every row
+        else if (h->wild_seed) { if (acgt_of((unsigned char)s[d + i]).find((char)h->alpha.ch[head[i]]) == std::string::npos) ++lvl; }
         else if ((int)head[i] != h->alpha.nch[(unsigned char)s[d + i]]) ++lvl;
       }
       if (!dead && lvl <= k) {
@@ -1507,7 +1560,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT ||
                            (h->sem == PM_SEM_EXACT_BASES && h->bases_flags);
   // edits on the seed family (A,C,G,T patterns of <= 32 characters): clusters and their DPs on the device
-  const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && h->pats.size() < ((size_t)1 << 22);
+  const bool cluster_dp = h->sem == PM_SEM_FILTER_BITVEC && h->edits_dev && !h->cfg.wildcards && h->pats.size() < ((size_t)1 << 22);
   const bool cluster = cluster_dp || device_cluster_plain(h);
   // exact_halves on the seed family: its per-pattern sequential rule as a sort + one walk per pattern
   // (pm_halves_rule).  Stateless, so only for a complete range on a fresh engine state.
@@ -1759,7 +1812,7 @@ extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, si
     std::vector<pm_hit> outv;
     const bool halves_whole = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && begin == 0 && end >= h->n &&
                               h->halves_fresh && h->carry.empty() && h->pats.size() < ((size_t)1 << 22) - 1;
-    if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && h->pats.size() < ((size_t)1 << 22)) || halves_whole ||
+    if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.wildcards && h->pats.size() < ((size_t)1 << 22)) || halves_whole ||
         (device_cluster_plain(h) && h->kern == PM_KERNEL_SEED)) {
       // clusters and their DPs on the device (pm_cluster_dp); only what it hands back goes through the host stage
       outv.resize((h->seed_flags ? 2 * cnt : cnt) + h->carry.size() + 16);

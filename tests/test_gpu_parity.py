@@ -432,7 +432,7 @@ def test_iupac_wildcards_exact(seed):
         for i, p in enumerate(pats):
             pm.add_pattern(p, i + 1)
         pm.init(codes, table)
-        assert pm.selected() == (sat_amd.SEM_SHIFT_AND, sat_amd.KERNEL_BITPAR)
+        assert pm.selected()[0] == sat_amd.SEM_SHIFT_AND             # (-w on an A,C,G,T,N stream: the seed family takes the primers it can expand)
         got = sat_amd.sorted_tuples(pm.find_all())
         pm.close()
         assert got == want and len(want) > 0, (seed, tn, len(want), len(got))
@@ -468,7 +468,7 @@ def test_iupac_wildcards_inexact(seed):
                         for i, p in enumerate(pats):
                             pm.add_pattern(p, i + 1)
                         pm.init(stream_codes, tbl)
-                        assert pm.selected()[1] == sat_amd.KERNEL_BITPAR
+                        assert pm.selected()[1] in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED)
                         hits = pm.find_all()
                         got = sat_amd.sorted_tuples(hits)
                         assert got == O.sorted_tuples(want), (seed, tbl is None, tn, k, indels, sem, len(got), len(want))
@@ -708,3 +708,43 @@ def test_exact_zones_on_the_seed_family(seed):
             # resumable: small consecutive ranges (seeds and chains across range edges) give the same hits
             assert sat_amd.sorted_tuples(pm.find_all(chunk=193)) == want, (seed, esb, eeb, sem, k, ind, "chunked")
             pm.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_ambiguous_primers_stay_on_the_seed_family(seed):
+    """-w with a few ambiguous primers in a set of plain ones (shift_and.cc:108-117: a pattern
+    character accepts the stream letters of its IUPAC compatibility set): primers with up to two
+    ambiguity letters are expanded into their concrete variants at table build and scanned by the
+    seed kernels; a primer with more goes to the bit-parallel residue engine beside them.  Exact,
+    -K 2 and -k 2; hit sets vs the oracle."""
+    rng = np.random.default_rng(1500 + seed)
+    ents = synth.make_entries(rng, 3, int(rng.integers(1500, 4000)), n_runs=3, repeats=(seed % 2 == 0))
+    L = int(rng.integers(20, 26))
+    pats = synth.make_patterns(rng, ents, 300, length=L, planted=0.7, indel_frac=0.3, extras=False)
+    amb = 0
+    for i in range(0, len(pats), 9):                                   # every ninth primer gets one or two ambiguity letters
+        p = list(pats[i])
+        for _ in range(1 + (i // 9) % 2):
+            p[int(rng.integers(0, len(p)))] = str(rng.choice(list("RYKMSWBDHVN")))
+        pats[i] = "".join(p)
+        amb += 1
+    p = list(pats[1])                                                  # one primer beyond the expansion limit
+    for j in (2, 5, 9, 13):
+        p[j] = "N"
+    pats[1] = "".join(p)
+    allp = pats + [synth.revcomp_iupac(q) for q in pats]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    for k, indels in ((0, True), (2, False), (2, True)):
+        eng = 4 if k == 0 else 5
+        want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=indels, wildcards=True, text_n=False))
+        pm = sat_amd.PatternMatch(k=k, indels=indels, wildcards=True, text_n=False)
+        for i, q in enumerate(allp):
+            pm.add_pattern(q, i + 1)
+        pm.init(codes, table)
+        assert pm.selected()[1] == sat_amd.KERNEL_SEED and "patterns the seed plan does not take" in pm.describe(), pm.describe()
+        got = sat_amd.sorted_tuples(pm.find_all())
+        assert got == want and len(want) > 20, (seed, k, indels, len(want), len(got))
+        assert sat_amd.sorted_tuples(pm.find_all(chunk=997)) == want, (seed, k, indels, "chunked")
+        pm.close()
