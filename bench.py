@@ -92,6 +92,23 @@ class CudaArray:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+def host_cores():
+    """CPUs this process can really use: its affinity mask, capped by the cgroup's CPU quota (a GPU box
+    hands a job a share of the host, not the host)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(args, stream0, primers_fwd, log):
     """The reference CPU path on a bounded sample of the same workload (BASELINE.md
     "CPU-baseline plan"): the real `primer_match -c` (oracle/_ref/, the reference compiled where it
@@ -135,10 +152,7 @@ def cpu_baseline(args, stream0, primers_fwd, log):
         dt, _ = O.time_find_all(text, allp, engine=O.pick_engine(text, allp, k, indels), k=k, indels=indels)
         return {"value": sample / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
                 "sample": "first %d bases of the rank-0 shard, all %d primers x 2 strands, scan only %.1f s" % (sample, len(primers_fwd), dt)}
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
+    ncores = host_cores()
     if args.cpu_procs > 0:
         ncores = min(ncores, args.cpu_procs)
     with tempfile.TemporaryDirectory() as d:
@@ -148,12 +162,15 @@ def cpu_baseline(args, stream0, primers_fwd, log):
         if not (write_db(os.path.join(d, "tiny.fa"), stream0[:2048].cpu().numpy()) and write_db(os.path.join(d, "db.fa"), stream0[:sample].cpu().numpy())):
             log("cpu_baseline: compress_seq failed")
             return None
+        log("cpu_baseline: reference primer_match on 2 kb (pattern index build) ...")
         t0 = time.time()
         r0 = subprocess.run(command(os.path.join(d, "tiny.fa"), pat), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         t_build = time.time() - t0
+        log("cpu_baseline: %.1f s; now on %d bases ..." % (t_build, sample))
         t0 = time.time()
         r1 = subprocess.run(command(os.path.join(d, "db.fa"), pat), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         t_all = time.time() - t0
+        log("cpu_baseline: %.1f s; %d processes next" % (t_all, ncores))
         if r0.returncode or r1.returncode:
             log("cpu_baseline: primer_match failed: " + (r1.stderr or r0.stderr).decode("latin1")[-300:])
             return None

@@ -36,7 +36,7 @@ for name, dst in (("kt_k1e", "k1_edits"), ("kt_k2e", "k2_edits")):
     src = one(os.path.join(G, "lines_" + tag, name, "*", "*kernel_stats.csv"))
     if src:
         shutil.copy(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (tag, dst)))
-for name in ("bench_K2", "bench_k0", "bench_K1", "bench_k1_edits", "bench_k2_edits", "bench_K2_1M"):
+for name in ("bench_K2", "bench_k0", "bench_K1", "bench_k1_edits", "bench_k2_edits", "bench_K2_1M", "bench_bitpar_k0_200k", "bench_bitpar_K2_200k", "bench_bitpar_k2_200k"):
     src = os.path.join(G, "lines_" + tag, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, "%s_%s.json" % (tag, name)))
@@ -52,11 +52,11 @@ for name in ("pmc_fetch_K2", "pmc_write_K2", "pmc_fetch_K0", "pmc_l2_K2"):
     hdr = rows[0]
     kn, cn, cv = hdr.index("Kernel_Name"), hdr.index("Counter_Name"), hdr.index("Counter_Value")
     for x in rows[1:]:
-        if "pm_seed_scan" in x[kn]:
+        if "pm_seed_scan" in x[kn] or "pm_pair_scan" in x[kn]:
             counters[(name, x[cn])] = counters.get((name, x[cn]), 0.0) + float(x[cv])
 
 entries = []
-for k, fetch, write, kernel in ((2, "pmc_fetch_K2", "pmc_write_K2", "pm_seed_scan<20,1,false>"), (0, "pmc_fetch_K0", None, "pm_seed_scan<20,2,false>")):
+for k, fetch, write, kernel in ((2, "pmc_fetch_K2", "pmc_write_K2", "pm_pair_scan"), (0, "pmc_fetch_K0", None, "pm_seed_scan<20,2,false>")):
     fs = counters.get((fetch, "FETCH_SIZE"))
     if fs is None:
         continue

@@ -149,17 +149,29 @@ __device__ __forceinline__ void pair_verify(const PairArgs &a, int combo, int64_
   const int L = a.pat_len[pi];
   const int64_t start = p + 1 - L;
   if (start < 0) return;
-  const uint32_t *pc = reinterpret_cast<const uint32_t *>(a.pat_codes + (size_t)pi * 32);
+  // all 32 pattern codes and the 32 stream bytes from `start` at once (every load independent of the
+  // others: this kernel is a chain of dependent loads as it is), per-byte verdicts by SWAR
+  const uint4 *pcv = reinterpret_cast<const uint4 *>(a.pat_codes + (size_t)pi * 32);
+  const uint4 pc0 = pcv[0], pc1 = pcv[1];
+  uint32_t tw[8];
+  if (start + 32 <= a.n) {
+    uint4 t0, t1;
+    __builtin_memcpy(&t0, a.text + start, 16);
+    __builtin_memcpy(&t1, a.text + start + 16, 16);
+    tw[0] = t0.x; tw[1] = t0.y; tw[2] = t0.z; tw[3] = t0.w; tw[4] = t1.x; tw[5] = t1.y; tw[6] = t1.z; tw[7] = t1.w;
+  } else {                                            // the last bytes of the stream
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      tw[d] = 0;
+      for (int b = 0; b < 4; ++b) { const int64_t q = start + 4 * d + b; if (q < a.n) tw[d] |= (uint32_t)a.text[q] << (8 * b); }
+    }
+  }
+  const uint32_t pcw[8] = {pc0.x, pc0.y, pc0.z, pc0.w, pc1.x, pc1.y, pc1.z, pc1.w};
   const uint32_t eb = (uint32_t)(a.eos_code & 0xff) * 0x01010101u;
   uint32_t mism = 0, eos = 0;                         // bit i: stream byte i differs from the pattern / is EOS
-#pragma unroll 1
-  for (int d = 0; 4 * d < L; ++d) {
-    const int64_t off = start + 4 * d;
-    uint32_t tw = 0;
-    if (off + 4 <= a.n) __builtin_memcpy(&tw, a.text + off, 4);
-    else
-      for (int b = 0; off + b < a.n; ++b) tw |= (uint32_t)a.text[off + b] << (8 * b);   // last bytes of the stream
-    const uint32_t x = tw ^ pc[d], z = tw ^ eb;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const uint32_t x = tw[d] ^ pcw[d], z = tw[d] ^ eb;
     const uint32_t y = (x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
     const uint32_t e = ~(z | ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
     mism |= (((y >> 7) & 1u) | ((y >> 14) & 2u) | ((y >> 21) & 4u) | ((y >> 28) & 8u)) << (4 * d);
@@ -747,7 +759,7 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   hipLaunchKernelGGL(pm_pair_scan, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
   hipError_t ce = hipGetLastError();
   if (ce != hipSuccess) return ce;
-  hipLaunchKernelGGL(pm_pair_verify, dim3(256 * 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pm_pair_verify, dim3(256 * 16), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
