@@ -34,7 +34,7 @@ struct PairTables {                                 // one pattern tile
   int fa[PAIR_MAX_COMBOS] = {}, fb[PAIR_MAX_COMBOS] = {};   // key fields of every combo (a < b), the other two are (c < d)
   std::vector<uint32_t> image;                      // [combo][PAIR_IMAGE_WORDS]
   std::vector<uint32_t> entries;                    // [combo][2 * distinct keys]: see pm_pair.hip
-  std::vector<int16_t> direct;                      // [combo][2^20]: direct-mapped by key, six bases of the first pattern | 0x8000 = several
+  std::vector<int16_t> direct;                      // [combo][2^20]: direct-mapped by key, six bases of the first pattern | -(k+1) or -8 (several) in the top four bits
   std::vector<uint32_t> first_pat;                  // [combo][distinct keys + 1]: first index into order[] of every key
   std::vector<uint32_t> order;                      // [combo][np]: pattern indices sorted by key
   size_t entries_off[PAIR_MAX_COMBOS] = {}, first_off[PAIR_MAX_COMBOS] = {};   // per combo, in elements of the arrays above

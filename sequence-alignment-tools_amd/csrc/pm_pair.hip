@@ -388,9 +388,11 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       PM_PAIR_OTHER(8) PM_PAIR_OTHER(9) PM_PAIR_OTHER(10) PM_PAIR_OTHER(11) PM_PAIR_OTHER(12) PM_PAIR_OTHER(13) PM_PAIR_OTHER(14) PM_PAIR_OTHER(15)
 #undef PM_PAIR_OTHER
       const uint32_t x = (uint32_t)E[j] ^ w;
-      // substitutions on the six bases; an entry shared by several patterns (bit 15, sign-extended: -8) always passes
+      // substitutions on the six bases, minus k + 1 (the entry's top four bits, sign-extended: -(k+1), or
+      // -8 when several patterns share the key): negative = suspicious; the sign bits are funnelled
+      // into sacc (v_bcnt with accumulator, v_alignbit: no compare)
       const int z = __popc((x | (x >> 1)) & 0x555u) + (E[j] >> 12);
-      sacc = (sacc << 1) | (z <= a.k ? 1u : 0u);
+      sacc = __builtin_amdgcn_alignbit(sacc, (uint32_t)z, 31);
     }
     return __brev(sacc) >> 24;
   };
@@ -643,9 +645,10 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
       const uint64_t slot = slot_pack(o[0], o[1], o[2], (uint32_t)std::min<size_t>(j2 - j, 4));
       const uint32_t ex = (uint32_t)slot;
       e.push_back(ex); e.push_back((uint32_t)(slot >> 32));
-      // direct-mapped by key: six bases of the first pattern's other fields, bit 15 = further patterns share the key
+      // direct-mapped by key: six bases of the first pattern's other fields; top four bits = -(k + 1), or -8 when
+      // further patterns share the key (what the consume stage adds to its mismatch count: negative = suspicious)
       const uint32_t key = (bitpos >> 5) | ((bitpos & 31u) << 15);
-      dir[key] = (int16_t)(uint16_t)((ex & 0xfffu) | (j2 - j > 1 ? 0x8000u : 0u));
+      dir[key] = (int16_t)(uint16_t)((ex & 0xfffu) | (j2 - j > 1 ? 0x8000u : ((uint32_t)(16 - (k + 1)) << 12)));
       j = j2;
     }
     f.push_back((uint32_t)np);
