@@ -37,6 +37,7 @@ struct SeedTables {
   int hfast = 0;                                  // see SeedArgs::hfast
   bool exact_filter = false;                      // see SeedArgs::exact_filter
   int edits = 0;                                  // > 0: edit-distance seed plan for this k (records in pat_codes)
+  std::vector<uint8_t> etable;                    // edits: [combo][2^21] key-hash table of pm_edit_scan (0 none, 1..254 fingerprint, 255 several)
   int eos_code = -1;
   std::vector<uint32_t> part32;
   std::vector<uint8_t> part_len, part_side;
@@ -47,7 +48,8 @@ struct SeedDevice {
   uint32_t *bloom = nullptr, *slots = nullptr, *pat_id = nullptr, *bitmap2 = nullptr;
   int lb2 = 0;
   void *pat40 = nullptr, *d_args = nullptr;
-  uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr;
+  uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr, *etable = nullptr;
+  bool edit_tabulated = false;                    // edits: the first stage is pm_edit_scan (PM_EDIT_SCAN=bloom selects the older pm_seed_scan instance)
   uint32_t *part32 = nullptr;
   bool halves = false; int hk = 0, hfast = 0, eos_code = -1, edits = 0;
   bool exact_filter = false;

@@ -31,6 +31,8 @@
 #include <algorithm>
 #include <cstring>
 #include <thread>
+#include <type_traits>
+#include <utility>
 
 namespace pm {
 
@@ -78,6 +80,7 @@ struct SeedArgs {
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
   const uint8_t *part_len, *part_side;  // its length; 0 = partner lies to the right of the seed, 1 = to the left
   const uint32_t *packed;               // the stream, 2 bits per base, 16 bases per dword (pack_stream); the first stage reads this
+  const uint8_t *etable;                // pm_edit_scan: [combo][2^21] direct-mapped byte table of the key hashes
   int64_t npacked;                      // dwords in `packed`
   const SeedArgs *self;                 // device copy of this struct, for the out-of-line rare paths
 };
@@ -917,6 +920,380 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
   if (EDITS && lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
 }
 
+// ---- edit-distance plan, first stage: pm_edit_scan ------------------------------------------------
+//
+// Same seeds as the EDITS instance of pm_seed_scan -- three clean 4-base pieces of the seeded window
+// under one of the displacement patterns edit_cover chose -- with a first stage built around two
+// facts: every piece is one BYTE of the 2-bit packed stream at some bit offset, and the (combo,
+// displacement) pairs of one combo only differ in WHICH bytes they combine.
+//   * The key hash is tabulated per piece: H = F0(first piece) ^ F1(second) ^ F2(third), F = 24-bit
+//     multiply + fold of one byte (edit_piece_hash).  A lane computes the F values of the bytes its
+//     eight windows can use once per half block (two SDWA instructions per value: the byte select rides
+//     on the multiply) and every test is then one three-way XOR (v_bitop3) of registers picked at compile time --
+//     no funnel shifts, no piece merging, no multiply per test.
+//   * The combo's filter in LDS is a blocked Bloom filter addressed by H itself: dword at byte
+//     H & 0x1fffc, bits (H >> 16) & 31, (H >> 24) & 31, (H >> 19) & 31 (three SDWA shifts).
+//   * Survivors (12 % at 200k patterns) look their key up in a direct-mapped byte table in L2
+//     (2 MiB per combo, slot = H >> 11: 0 = no key, 1..254 = the key's fingerprint H & 0xff, 255 =
+//     several keys): a branch-free one-byte load per test -- non-survivors read slot 0, one cached line
+//     -- consumed one unit later.  That replaces the compaction of every Bloom survivor into an LDS
+//     queue and the second-level bitmap: only the ~1.3 % of the tests that are real 12-base key matches
+//     are compacted (ballot + mbcnt), probed in the bucket table and put to the q-gram test.
+// One instance per combo (pieces and displacement list are template parameters: all register indices
+// and stream offsets are immediates); the lists are edit_cover's, checked on the host at upload.
+constexpr uint32_t EDIT_MUL0 = 0x9E3779u, EDIT_MUL1 = 0xC2B2AFu, EDIT_MUL2 = 0x85EBCBu;
+constexpr int EDIT_TABLE_BITS = 21;
+constexpr int EDIT_QCAP = SEED_QCAP + SEED_Q2CAP;                  // suspicious windows per wave (8-byte entries)
+__device__ __host__ __forceinline__ uint32_t edit_piece_hash(uint32_t g, uint32_t mul) {
+  const uint32_t y = g * mul;                                      // g < 256, mul < 2^24: no overflow
+  return y ^ (y >> 16);
+}
+constexpr int EVD1[13] = {0, 0, 0, 1, -1, 0, 0, 2, -2, 1, 1, -1, -1};   // displacement second - third piece
+constexpr int EVD2[13] = {0, 1, -1, 0, 0, 2, -2, 0, 0, 1, -1, 1, -1};   // first - second piece
+struct EditVariants {
+  int n;
+  int sa[13], sb[13];                                              // displacement of the first and second piece, variants sorted by sb
+  int lo_a, hi_a, lo_b, hi_b;
+};
+constexpr EditVariants edit_variants(uint32_t evar) {
+  EditVariants L{};
+  L.n = 0; L.lo_a = 0; L.hi_a = 0; L.lo_b = 0; L.hi_b = 0;
+  for (int i = 0; i < 13; ++i) { L.sa[i] = 0; L.sb[i] = 0; }
+  for (int s = -2; s <= 2; ++s)
+    for (int v = 0; v < 13; ++v)
+      if (((evar >> v) & 1u) && EVD1[v] == s) {
+        const int sa = EVD1[v] + EVD2[v];
+        L.sa[L.n] = sa; L.sb[L.n] = s; ++L.n;
+        if (sa < L.lo_a) L.lo_a = sa;
+        if (sa > L.hi_a) L.hi_a = sa;
+        if (s < L.lo_b) L.lo_b = s;
+        if (s > L.hi_b) L.hi_b = s;
+      }
+  return L;
+}
+// the displacement lists edit_cover finds for the combos of the k = 1 and k = 2 plans (bit v = pattern v)
+constexpr uint32_t edit_cover_of(int qa, int qb, int qc) {
+  const int c = qa * 100 + qb * 10 + qc;
+  return c == 12 ? 0x1u : c == 13 ? 0x19u : c == 14 ? 0x199u : c == 23 ? 0x7u : c == 24 ? 0x1e1fu : c == 34 ? 0x67u :
+         c == 123 ? 0x1u : c == 124 ? 0x19u : c == 134 ? 0x7u : c == 234 ? 0x1u : 0u;
+}
+
+template <int N, class Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+// 32 bits from bit O (compile time) of the 96-bit string p2 : p1 : cur (bit 0 = bit 0 of p2)
+template <int O>
+__device__ __forceinline__ uint32_t bits_at(uint32_t p2, uint32_t p1, uint32_t cur) {
+  static_assert(O >= 0 && O < 96, "offset");
+  if constexpr (O == 0) return p2;
+  else if constexpr (O < 32) return __builtin_amdgcn_alignbit(p1, p2, O);
+  else if constexpr (O == 32) return p1;
+  else if constexpr (O < 64) return __builtin_amdgcn_alignbit(cur, p1, O - 32);
+  else if constexpr (O == 64) return cur;
+  else return cur >> (O - 64);
+}
+// F of the byte at bit B of p2 : p1 : cur: the byte is picked by the multiply's operand selector
+template <int B>
+__device__ __forceinline__ uint32_t piece_hash_at(uint32_t p2, uint32_t p1, uint32_t cur, uint32_t mul) {
+  constexpr int PH = B & 7, R = (B - PH) / 8, O = PH + 32 * (R / 4), T = R % 4;
+  const uint32_t w = bits_at<O>(p2, p1, cur);
+  uint32_t y, f;
+  if constexpr (T == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(y) : "v"(w), "v"(mul));
+  else if constexpr (T == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(y) : "v"(w), "v"(mul));
+  else if constexpr (T == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(y) : "v"(w), "v"(mul));
+  else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(y) : "v"(w), "v"(mul));
+  asm("v_xor_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(f) : "v"(y));
+  return f;
+}
+typedef __attribute__((address_space(3))) uint32_t lds_w32;
+
+// the q-gram test of edits_plausible on the 2-bit packed stream (what the raw bytes pack to: same verdicts)
+__device__ __forceinline__ bool edits_plausible_packed(const SeedArgs &a, int64_t p, uint32_t pi) {
+  const int k = a.edits;
+  if (p - 21 < 0 || p + 3 > a.n) return true;
+  const uint2 pp = a.pat40[pi];
+  const uint64_t P = ((uint64_t)pp.y << 32) | pp.x;
+  const int64_t b0 = p - 21, d = b0 >> 4;
+  const uint32_t o = 2u * (uint32_t)(b0 & 15);
+  const uint32_t w0 = a.packed[d], w1 = d + 1 < a.npacked ? a.packed[d + 1] : 0u, w2 = d + 2 < a.npacked ? a.packed[d + 2] : 0u;
+  const uint32_t tl = o ? __builtin_amdgcn_alignbit(w1, w0, o) : w0, th = o ? __builtin_amdgcn_alignbit(w2, w1, o) : w1;
+  const uint64_t T = ((uint64_t)th << 32) | tl;                    // stream p-21 .. p+2 (the low 48 bits)
+  uint64_t M = 0;
+#pragma unroll
+  for (int dd = -2; dd <= 2; ++dd) {
+    if (dd < -k || dd > k) continue;
+    const uint64_t x = (P ^ (T >> (2 * (2 + dd)))) & 0xffffffffffull;
+    const uint64_t z = x | (x >> 2) | (x >> 4) | (x >> 6);
+    M |= ~(z | (z >> 1));
+  }
+  return (int)__popcll(M & 0x155555555ull) >= 17 - 4 * k;
+}
+
+template <int QA, int QB, int QC, uint32_t EVAR>
+__device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int combo, const int cj, uint32_t *lds) {
+  constexpr EditVariants VL = edit_variants(EVAR);
+  constexpr int NV = VL.n, LOA = VL.lo_a, HIA = VL.hi_a, LOB = VL.lo_b, HIB = VL.hi_b;
+  constexpr int NA = 8 + HIA - LOA, NB = 8 + HIB - LOB;
+  static_assert(NV >= 1 && QA < QB && QB < QC && QC <= 4 && QB <= 3, "combo");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint2 *queue = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_STRIDE) + wave * EDIT_QCAP;
+  const int64_t sub = a.chunk_len / WAVES;
+  const int64_t ws = (a.chunk0 + cj) * a.chunk_len + (int64_t)wave * sub;
+  // p = last base of the 20-base window; a candidate end e comes from seeds at p = e-1+-k
+  const int64_t p_lo = a.begin - a.edits, p_hi = a.end + a.edits;
+  int64_t own_lo = ws > p_lo ? ws : p_lo;
+  int64_t own_hi = ws + sub;
+  if (own_hi > p_hi) own_hi = p_hi;
+  if (own_hi > a.n) own_hi = a.n;
+  if (own_lo < 19) own_lo = 19;
+  if (own_lo >= own_hi) return;
+
+  const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo], sel = a.perm_sel[combo];
+  const uint32_t ema = a.emask_a[combo], emb = a.emask_b[combo];
+  const uint4 *buckets = a.buckets + (size_t)combo * 2 * ((size_t)1 << (32 - a.bucket_shift));
+  const uint8_t *etable = a.etable + ((size_t)combo << EDIT_TABLE_BITS);
+  const uint32_t imask = (1u << a.idx_bits) - 1u;
+  uint32_t carry1, carry2;
+  {
+    const uint32_t pk = load_packed<false>(a.packed, a.npacked, ws - 32 + 16 * (lane & 1));
+    carry2 = __builtin_amdgcn_readlane(pk, 0);
+    carry1 = __builtin_amdgcn_readlane(pk, 1);
+  }
+  int qn = 0;                                                     // wave-uniform queue fill
+  unsigned long long ob_next = 0;                                 // seed records go to slots reserved SEED_OUT_BLOCK at a time
+  int ob_left = 0;
+  auto emit = [&](bool pass, int64_t p, uint32_t pi) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(pass);
+    if (bal == 0) return;
+    const int c = __popcll(bal);
+    if (c > ob_left) {
+      if (lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+      ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)base);
+      ob_left = SEED_OUT_BLOCK;
+    }
+    if (pass) {
+      const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, pi);
+    }
+    ob_next += c; ob_left -= c;
+  };
+  // bucket probe + q-gram test of whole batches of 64 queued windows (all: of what is left, too)
+  auto process = [&](bool all) __attribute__((always_inline)) {
+    while (qn >= 64 || (all && qn > 0)) {
+      const int cnt = qn >= 64 ? 64 : qn;
+      qn -= cnt;
+      if (a.debug & 2) continue;
+      const bool on = lane < cnt;
+      uint32_t h2 = 0, mm = 0, pidx = 0;
+      int64_t p = 0;
+      uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+      uint2 e = make_uint2(0, 0);
+      if (on) {
+        e = queue[qn + lane];
+        p = ws + (e.y >> 8);
+        h2 = window_hash<1>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
+        const size_t b = h2 >> a.bucket_shift;
+        b0 = buckets[2 * b]; b1 = buckets[2 * b + 1];
+        mm = match_mask(b0, b1, h2 << a.idx_bits, imask);
+      }
+      const uint32_t sl[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      if (mm & 255u) {
+        const int sidx = __ffs(mm) - 1;
+        uint32_t slot = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
+        pidx = slot & imask;
+      }
+      bool pass = false;
+      if ((mm & 255u) && !(a.debug & 4)) pass = edits_plausible_packed(a, p, pidx);
+      emit(pass, p, pidx);
+      if ((mm & 511u) && !(a.debug & 4)) {
+        uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);           // matches beyond the first (rare)
+        while (rest) {
+          const int sidx = __ffs(rest) - 1;
+          rest &= rest - 1;
+          uint32_t slot = 0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
+          verify_edits(a.self, p, slot & imask);
+        }
+        if (mm & 256u) probe_from<false, true>(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, ((uint64_t)(e.y & 0xffu) << 32) | e.x, p);
+      }
+    }
+  };
+
+  uint32_t q0 = load_packed<false>(a.packed, a.npacked, ws + 16 * lane);
+  uint32_t q1 = ws + 1024 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 1024 + 16 * lane) : 0u;
+  uint32_t q2 = ws + 2048 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
+  uint32_t q3 = ws + 3072 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
+  const uint32_t mul0 = EDIT_MUL0, mul1 = EDIT_MUL1, mul2 = EDIT_MUL2;
+  for (int64_t bb = ws; bb < own_hi; bb += 1024) {
+    const uint32_t cur = q0;
+    q0 = q1; q1 = q2; q2 = q3;
+    if (bb + 4096 < own_hi) q3 = load_packed<false>(a.packed, a.npacked, bb + 4096 + 16 * lane);
+    const uint32_t prev1 = __builtin_amdgcn_update_dpp(carry1, cur, 0x138, 0xf, 0xf, false);       // wave_shr:1
+    const uint32_t prev2 = __builtin_amdgcn_update_dpp(carry2, prev1, 0x138, 0xf, 0xf, false);
+    carry2 = __builtin_amdgcn_readlane(cur, 62);
+    carry1 = __builtin_amdgcn_readlane(cur, 63);
+    const int64_t pbase = bb + 16 * lane;
+    uint32_t own = 0xffffu;
+    if (bb < own_lo || bb + 1024 > own_hi) {                       // wave-uniform: edge blocks only
+      const int64_t lo = own_lo - pbase, hi = own_hi - pbase;
+      const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
+      own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
+    }
+    uint32_t sus[NV];                                              // per displacement pattern: the lane's suspicious windows
+    static_for<NV>([&](auto V) __attribute__((always_inline)) { sus[decltype(V)::value] = 0; });
+
+    static_for<2>([&](auto HH) __attribute__((always_inline)) {
+      constexpr int HALF = decltype(HH)::value;
+      // window i = 8 HALF + j of the lane starts at bit 26 + 2 i of prev2 : prev1 : cur, its piece q at + 8 q,
+      // displaced by s bases at + 2 s
+      uint32_t FA[NA], FB[NB], FC[8];
+      static_for<NA>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        FA[t] = piece_hash_at<26 + 2 * (8 * HALF + LOA + t) + 8 * QA>(prev2, prev1, cur, mul0);
+      });
+      static_for<NB>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        FB[t] = piece_hash_at<26 + 2 * (8 * HALF + LOB + t) + 8 * QB>(prev2, prev1, cur, mul1);
+      });
+      static_for<8>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        FC[t] = piece_hash_at<26 + 2 * (8 * HALF + t) + 8 * QC>(prev2, prev1, cur, mul2);
+      });
+
+      uint32_t Hb[2][8], Eb[2][8], surv[2] = {0, 0};
+      // consume stage of a unit: its table bytes have landed.  Suspicious = the byte equals the key's
+      // fingerprint, or says "several keys" (255); the sign of t funnels into sacc
+      auto consume = [&](auto PP) __attribute__((always_inline)) -> uint32_t {
+        constexpr int P = decltype(PP)::value;
+        uint32_t sacc = 0;
+        static_for<8>([&](auto J) __attribute__((always_inline)) {
+          constexpr int j = decltype(J)::value;
+          uint32_t x;
+          asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(x) : "v"(Eb[P][j]), "v"(Hb[P][j]));
+          const uint32_t t = (x - 1u) | ((Eb[P][j] << 23) + 0x800000u);
+          uint32_t &sr = sacc;
+          asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(sr) : "v"(t));   // (volatile: stays here, see the test stage)
+        });
+        return (__brev(sacc) >> 24) & surv[P] & ((own >> (8 * HALF)) & 0xffu);
+      };
+      static_for<NV>([&](auto VV) __attribute__((always_inline)) {
+        constexpr int V = decltype(VV)::value, P = V & 1;
+        constexpr int SA = VL.sa[V], SB = VL.sb[V];
+        __builtin_amdgcn_sched_barrier(0);                          // one unit at a time: hashes of later units computed early only cost registers
+        uint32_t wd[8];
+        static_for<8>([&](auto J) __attribute__((always_inline)) {
+          constexpr int j = decltype(J)::value;
+          Hb[P][j] = __builtin_amdgcn_bitop3_b32(FA[j + SA - LOA], FB[j + SB - LOB], FC[j], 0x96);   // three-way XOR
+          wd[j] = *reinterpret_cast<lds_w32 *>((uintptr_t)(Hb[P][j] & 0x1fffcu));
+        });
+        __builtin_amdgcn_sched_barrier(0);                          // the eight reads go out before the first verdict waits
+        uint32_t acc = 0;
+        static_for<8>([&](auto J) __attribute__((always_inline)) {
+          constexpr int j = decltype(J)::value;
+          const uint32_t H = Hb[P][j], Jx = H >> 11;
+          uint32_t s1, s2, s3;
+          asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(s1) : "v"(H), "v"(wd[j]));
+          asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s2) : "v"(H), "v"(wd[j]));
+          asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(s3) : "v"(Jx), "v"(wd[j]));
+          const uint32_t v = s1 & s2 & s3;
+          // (volatile: the funnel stays here -- left to the scheduler it sinks to the consume stage and the eight verdicts are spilled)
+          asm volatile("v_alignbit_b32 %0, %1, %0, 1" : "+v"(acc) : "v"(v));
+          const uint32_t off = Jx & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1);   // the key's slot for a survivor, slot 0 otherwise
+          Eb[P][j] = etable[off];
+        });
+        surv[P] = acc >> 24;
+        if constexpr (V > 0) sus[V - 1] |= consume(std::integral_constant<int, P ^ 1>{}) << (8 * HALF);
+      });
+      sus[NV - 1] |= consume(std::integral_constant<int, (NV - 1) & 1>{}) << (8 * HALF);
+    });
+
+    // compaction of the suspicious windows, one per lane and round (ballot + mbcnt give the queue slots)
+    if (!(a.debug & 1)) {
+#pragma unroll 1
+      for (int v = 0; v < NV; ++v) {
+        uint32_t rem = 0;
+        int sa = 0, sb = 0;
+        static_for<NV>([&](auto T) __attribute__((always_inline)) {
+          constexpr int t = decltype(T)::value;
+          if (v == t) { rem = sus[t]; sa = VL.sa[t]; sb = VL.sb[t]; }
+        });
+        for (;;) {
+          const unsigned long long bal = __ballot(rem != 0);
+          if (bal == 0) break;
+          if (qn + 64 > EDIT_QCAP) process(false);
+          if (rem != 0) {
+            const int i = __ffs(rem) - 1;
+            __builtin_assume(i >= 0 && i < 16);
+            rem &= rem - 1;
+            const int sft = 2 * i + 26;
+            const uint32_t x0 = __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = __builtin_amdgcn_alignbit(cur, prev1, sft),
+                           x2 = cur >> (sft & 31);
+            uint32_t wlo = sft < 32 ? x0 : x1;
+            const uint32_t whi = sft < 32 ? x1 : x2;
+            if (sa | sb) {                                         // wave-uniform
+              const int fa = sft + 2 * sa, fb = sft + 2 * sb;
+              const uint32_t wa = fa < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, fa) : __builtin_amdgcn_alignbit(cur, prev1, fa);
+              const uint32_t wb = fb < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, fb) : __builtin_amdgcn_alignbit(cur, prev1, fb);
+              wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
+            }
+            const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+            queue[slot] = make_uint2(wlo, (whi & 0xffu) | ((uint32_t)(pbase + i - ws) << 8));
+          }
+          qn += __popcll(bal);
+        }
+      }
+    }
+    if (qn >= 128) process(false);
+  }
+  process(true);
+  if (lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
+}
+
+__global__ __launch_bounds__(SEED_THREADS) void pm_edit_scan(SeedArgs a) {
+  extern __shared__ uint32_t lds[];
+  const int per_super = a.group * a.ncombos;
+  const int sc = blockIdx.x / per_super;
+  const int rem = blockIdx.x - sc * per_super;
+  int combo = rem / a.group;
+  int cj = sc * a.group + (rem - combo * a.group);
+  const int full = (a.nchunks / a.group) * a.group;               // last, shorter superchunk
+  if (sc * a.group >= full) {
+    const int tail = a.nchunks - full;
+    const int r2 = blockIdx.x - (full / a.group) * per_super;
+    combo = r2 / tail;
+    cj = full + (r2 - combo * tail);
+  }
+  if (cj >= a.nchunks || combo >= a.ncombos) return;
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.bloom + (size_t)combo * SEED_BLOOM_STRIDE);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+    for (int i = threadIdx.x; i < SEED_BLOOM_STRIDE / 4; i += SEED_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  switch (a.perm_sel[combo] & 0xffffffu) {                          // wave-uniform: the combo's pieces
+    case 0x020100u: edit_scan_body<0, 1, 2, edit_cover_of(0, 1, 2)>(a, combo, cj, lds); break;
+    case 0x030100u: edit_scan_body<0, 1, 3, edit_cover_of(0, 1, 3)>(a, combo, cj, lds); break;
+    case 0x040100u: edit_scan_body<0, 1, 4, edit_cover_of(0, 1, 4)>(a, combo, cj, lds); break;
+    case 0x030200u: edit_scan_body<0, 2, 3, edit_cover_of(0, 2, 3)>(a, combo, cj, lds); break;
+    case 0x040200u: edit_scan_body<0, 2, 4, edit_cover_of(0, 2, 4)>(a, combo, cj, lds); break;
+    case 0x040300u: edit_scan_body<0, 3, 4, edit_cover_of(0, 3, 4)>(a, combo, cj, lds); break;
+    case 0x030201u: edit_scan_body<1, 2, 3, edit_cover_of(1, 2, 3)>(a, combo, cj, lds); break;
+    case 0x040201u: edit_scan_body<1, 2, 4, edit_cover_of(1, 2, 4)>(a, combo, cj, lds); break;
+    case 0x040301u: edit_scan_body<1, 3, 4, edit_cover_of(1, 3, 4)>(a, combo, cj, lds); break;
+    case 0x040302u: edit_scan_body<2, 3, 4, edit_cover_of(2, 3, 4)>(a, combo, cj, lds); break;
+    default: break;
+  }
+}
+
 // Second kernel of the edit-distance plan: the seed list is dense (every lane has work), one seed
 // per lane, grid-stride; the seed count is read from device memory (no host round trip).
 struct EditVerifyArgs {
@@ -1236,8 +1613,12 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.bloom.assign((size_t)C * SEED_BLOOM_STRIDE, 0);
   int lb2 = 16;
   while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2;
+  if (edits) lb2 = 5;                              // pm_edit_scan has its byte table instead (the older first stage builds the bitmap on request)
+  const bool edit_bloom_v1 = edits && getenv("PM_EDIT_SCAN") && !strcmp(getenv("PM_EDIT_SCAN"), "bloom");
+  if (edit_bloom_v1) { lb2 = 16; while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2; }
   t.lb2 = lb2;
   t.bitmap2.assign((size_t)C << (lb2 - 5), 0);
+  if (edits && !edit_bloom_v1) t.etable.assign((size_t)C << EDIT_TABLE_BITS, 0);
   t.slots.assign((size_t)C * nslots, EMPTY);
   for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
   t.eos_code = -1;
@@ -1284,7 +1665,18 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
                                      : window_hash<2>(wlo, whi, mlo, mhi, t.perm_sel[ci], &ss);
       const uint32_t hsel = bloom_selectors(ss);
       static_assert(SEED_BLOOM_WORDS == 1 << 15, "block address = h >> 15");
-      if (t.exact_filter) {
+      if (!t.etable.empty()) {
+        // pm_edit_scan: tabulated key hash, filter block addressed by the hash itself, byte table by its top 21 bits
+        const uint64_t W = ((uint64_t)whi << 32) | wlo;
+        const uint32_t H = edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][0])) & 0xffu, EDIT_MUL0) ^
+                           edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][1])) & 0xffu, EDIT_MUL1) ^
+                           edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][2])) & 0xffu, EDIT_MUL2);
+        t.bloom[(size_t)ci * SEED_BLOOM_STRIDE + ((H & 0x1fffcu) >> 2)] |= (1u << ((H >> 16) & 31)) | (1u << ((H >> 24) & 31)) | (1u << ((H >> 19) & 31));
+        uint8_t &slot = t.etable[((size_t)ci << EDIT_TABLE_BITS) + (H >> 11)];
+        const uint32_t fp = H & 0xffu;
+        const uint8_t want = (fp == 0 || fp == 255u) ? (uint8_t)255 : (uint8_t)fp;
+        slot = slot == 0 ? want : (slot == want ? want : (uint8_t)255);
+      } else if (t.exact_filter) {
         const uint32_t key = wlo & mlo;                           // < 2^20 = the filter's bit count
         t.bloom[(size_t)ci * SEED_BLOOM_STRIDE + (key >> 5)] |= 1u << (key & 31u);
       } else {
@@ -1294,7 +1686,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
         for (int q = 0; q < 4; ++q) blk[q] |= (uint8_t)(bits >> (8 * q));
       }
       const uint32_t h2 = h * HASH_SLOT;
-      t.bitmap2[((size_t)ci << (lb2 - 5)) + (h2 >> (37 - lb2))] |= 1u << ((h2 >> (32 - lb2)) & 31);
+      if (t.etable.empty()) t.bitmap2[((size_t)ci << (lb2 - 5)) + (h2 >> (37 - lb2))] |= 1u << ((h2 >> (32 - lb2)) & 31);
       const uint32_t imask = (1u << idx_bits) - 1u;
       uint32_t b = h2 >> t.bucket_shift;
       uint32_t *tb = &t.slots[(size_t)ci * nslots];
@@ -1348,17 +1740,22 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
   d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code; d->exact_filter = t.exact_filter;
   d->edits = t.edits;
+  d->edit_tabulated = !t.etable.empty();
+  if (d->edit_tabulated && (e = up(t.etable.data(), t.etable.size(), (void **)&d->etable)) != hipSuccess) return e;
   for (int c = 0; c < d->ncombos; ++c) {              // byte masks of the combo's first and second piece (edits: displaced pieces)
     d->emask_a[c] = t.r >= 3 && t.combos[c][0] < 4 ? 0xffu << (8 * t.combos[c][0]) : 0u;
     d->emask_b[c] = t.r >= 3 && t.combos[c][1] < 4 ? 0xffu << (8 * t.combos[c][1]) : 0u;
   }
   if (t.edits) edit_cover(t.edits, t.k + t.r, t.combos, d->evar);
+  if (d->edit_tabulated)                              // pm_edit_scan's instances are compiled for these displacement lists
+    for (int c = 0; c < d->ncombos; ++c)
+      if (t.r != 3 || d->evar[c] == 0 || d->evar[c] != edit_cover_of(t.combos[c][0], t.combos[c][1], t.combos[c][2])) return hipErrorInvalidConfiguration;
   if ((e = hipMalloc(&d->d_args, 1024)) != hipSuccess) return e;
   static_assert(sizeof(SeedArgs) <= 1024, "argument block");
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
                            reinterpret_cast<const void *>(pm_seed_scan<20, 0, false>), reinterpret_cast<const void *>(pm_seed_scan<0, 0, false>),
                            reinterpret_cast<const void *>(pm_seed_scan<0, 0, true>),
-                           reinterpret_cast<const void *>(pm_seed_scan<20, 1, false, true>)};
+                           reinterpret_cast<const void *>(pm_seed_scan<20, 1, false, true>), reinterpret_cast<const void *>(pm_edit_scan)};
   for (const void *kf : kernels) {
     // bloom_block addresses the filter from LDS address 0: a kernel that acquired static LDS (which
     // the dynamic block would follow) must fail here, at init, not compute with a shifted filter
@@ -1371,7 +1768,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
 }
 
 void seed_free(SeedDevice *d) {
-  void *ptrs[] = {d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  void *ptrs[] = {d->etable, d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = SeedDevice();
 }
@@ -1424,6 +1821,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); memcpy(a.evar, d.evar, sizeof(a.evar)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
+  a.etable = nullptr; a.seed_out = nullptr;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
   if (!d.d_args) return hipErrorInvalidValue;
   a.self = reinterpret_cast<const SeedArgs *>(d.d_args);
@@ -1440,7 +1838,9 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
     // the rare out-of-line paths read the scan's view of the argument block
     ce = hipMemcpyAsync(d.d_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st);
     if (ce != hipSuccess) return ce;
-    hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, sa);
+    sa.etable = d.etable;
+    if (d.edit_tabulated) hipLaunchKernelGGL(pm_edit_scan, grid, block, SEED_LDS_BYTES, st, sa);
+    else hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, sa);
     if ((ce = hipGetLastError()) != hipSuccess) return ce;
     EditVerifyArgs v;
     v.a = a;
