@@ -37,7 +37,9 @@ struct SeedTables {
   int hfast = 0;                                  // see SeedArgs::hfast
   bool exact_filter = false;                      // see SeedArgs::exact_filter
   int edits = 0;                                  // > 0: edit-distance seed plan for this k (records in pat_codes)
-  std::vector<uint8_t> etable;                    // edits: [combo][2^21] key-hash table of pm_edit_scan (0 none, 1..254 fingerprint, 255 several)
+  std::vector<uint8_t> etable;                    // edits: per combo, key-hash bit map of pm_edit_scan (2^etable_log bits)
+  int etable_log = 0;
+  std::vector<uint32_t> eidx;                     // edits: pattern index of every bucket slot (the slots hold pattern pieces + fingerprint)
   int eos_code = -1;
   std::vector<uint32_t> part32;
   std::vector<uint8_t> part_len, part_side;
@@ -49,6 +51,8 @@ struct SeedDevice {
   int lb2 = 0;
   void *pat40 = nullptr, *d_args = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr, *etable = nullptr;
+  uint32_t *eidx = nullptr;
+  int etable_log = 0;
   bool edit_tabulated = false;                    // edits: the first stage is pm_edit_scan (PM_EDIT_SCAN=bloom selects the older pm_seed_scan instance)
   uint32_t *part32 = nullptr;
   bool halves = false; int hk = 0, hfast = 0, eos_code = -1, edits = 0;

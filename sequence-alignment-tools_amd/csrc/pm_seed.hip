@@ -80,7 +80,10 @@ struct SeedArgs {
   const uint32_t *part32;               // partner half, 2 bits per base (<= 16 bases)
   const uint8_t *part_len, *part_side;  // its length; 0 = partner lies to the right of the seed, 1 = to the left
   const uint32_t *packed;               // the stream, 2 bits per base, 16 bases per dword (pack_stream); the first stage reads this
-  const uint8_t *etable;                // pm_edit_scan: [combo][2^21] direct-mapped byte table of the key hashes
+  const uint8_t *etable;                // pm_edit_scan: [combo][2^et_bytes_log bytes] bit map of the key hashes
+  const uint32_t *eidx;                 // pm_edit_scan: pattern index of every bucket slot
+  int et_shift, et_bytes_log;           // the map: H >> et_shift = byte offset of the key's dword (& et_mask), 2^et_bytes_log bytes per combo
+  uint32_t et_mask;
   int64_t npacked;                      // dwords in `packed`
   const SeedArgs *self;                 // device copy of this struct, for the out-of-line rare paths
 };
@@ -451,28 +454,45 @@ __device__ __forceinline__ uint32_t edits_verify(const SeedArgs &a, int64_t p, u
 // stream at the 2k+1 displacements, zero test over 8-bit windows at 2-bit steps, OR, popcount:
 // random key matches pass with probability ~1e-6, real ones always (N and EOS pack to arbitrary
 // bases, which can only add words).
+// The q-gram count on 32-bit registers.  P = the pattern's last 20 bases (2 bits each), tl : th = the 24 stream
+// bases p-21 .. p+2.  Words 0..12 live in the low 32 bits of P ^ (T >> c); words 13..16 in bits 24..39, which
+// are handled two displacements per register (16 bits each; the zero test never looks across the halves for
+// the word offsets used).
+__device__ __forceinline__ bool qgram_close(uint32_t plo, uint32_t phi, uint32_t tl, uint32_t th, int k) {
+  const uint32_t tm = __builtin_amdgcn_alignbit(th, tl, 24);       // stream bits 24 .. 55
+  auto words = [](uint32_t x) __attribute__((always_inline)) -> uint32_t {   // bit 2j: the four bases from j on are equal
+    const uint32_t z = x | (x >> 2) | (x >> 4) | (x >> 6);
+    return ~(z | (z >> 1));
+  };
+  uint32_t mlo = 0, mhi = 0;
+  uint32_t pend = 0;
+  int npend = 0;
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) {
+    if (d < -k || d > k) continue;                                 // wave-uniform
+    const int c = 2 * (2 + d);
+    mlo |= words(plo ^ (c ? __builtin_amdgcn_alignbit(th, tl, c) : tl));
+    const uint32_t y = (phi ^ (tm >> c)) & 0xffffu;
+    if (npend == 0) { pend = y; npend = 1; }
+    else { mhi |= words(pend | (y << 16)); npend = 0; }
+  }
+  if (npend) mhi |= words(pend | 0xffff0000u);
+  mhi |= mhi >> 16;
+  return (int)(__popc(mlo & 0x1555555u) + __popc(mhi & 0x154u)) >= 17 - 4 * k;
+}
+
 __device__ __forceinline__ bool edits_plausible(const SeedArgs &a, int64_t p, uint32_t pi) {
-  const int k = a.edits;
   if (p - 21 < 0 || p + 3 > a.n) return true;                     // stream ends: let the automaton decide
-  const uint2 pp = a.pat40[pi];
-  const uint64_t P = ((uint64_t)pp.y << 32) | pp.x;               // base j of the last 20 at bits 2j
+  const uint2 pp = a.pat40[pi];                                   // base j of the last 20 at bits 2j
   uint64_t raw0, raw1, raw2;
   __builtin_memcpy(&raw0, a.text + p - 21, 8);
   __builtin_memcpy(&raw1, a.text + p - 13, 8);
   __builtin_memcpy(&raw2, a.text + p - 5, 8);
   const int sh = a.ascii ? 1 : 0;
-  const uint64_t T = (uint64_t)(pack4((uint32_t)raw0, sh) | (pack4((uint32_t)(raw0 >> 32), sh) << 8) |
-                                (pack4((uint32_t)raw1, sh) << 16) | (pack4((uint32_t)(raw1 >> 32), sh) << 24)) |
-                     ((uint64_t)(pack4((uint32_t)raw2, sh) | (pack4((uint32_t)(raw2 >> 32), sh) << 8)) << 32);   // stream p-21 .. p+2
-  uint64_t M = 0;
-#pragma unroll
-  for (int d = -2; d <= 2; ++d) {
-    if (d < -k || d > k) continue;                                 // wave-uniform
-    const uint64_t x = (P ^ (T >> (2 * (2 + d)))) & 0xffffffffffull;
-    const uint64_t z = x | (x >> 2) | (x >> 4) | (x >> 6);
-    M |= ~(z | (z >> 1));
-  }
-  return (int)__popcll(M & 0x155555555ull) >= 17 - 4 * k;               // words j = 0..16 at bits 2j
+  const uint32_t tl = pack4((uint32_t)raw0, sh) | (pack4((uint32_t)(raw0 >> 32), sh) << 8) |
+                      (pack4((uint32_t)raw1, sh) << 16) | (pack4((uint32_t)(raw1 >> 32), sh) << 24);
+  const uint32_t th = pack4((uint32_t)raw2, sh) | (pack4((uint32_t)(raw2 >> 32), sh) << 8);   // stream p-21 .. p+2
+  return qgram_close(pp.x, (((pp.y & 0xffu) << 8) | (pp.x >> 24)), tl, th, a.edits);
 }
 
 __device__ __forceinline__ pm_hit edit_record(int64_t end, uint32_t pid, uint32_t lvl1) {
@@ -933,17 +953,17 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 //     no funnel shifts, no piece merging, no multiply per test.
 //   * The combo's filter in LDS is a blocked Bloom filter addressed by H itself: dword at byte
 //     H & 0x1fffc, bits (H >> 16) & 31, (H >> 24) & 31, (H >> 19) & 31 (three SDWA shifts).
-//   * Survivors (12 % at 200k patterns) look their key up in a direct-mapped byte table in L2
-//     (2 MiB per combo, slot = H >> 11: 0 = no key, 1..254 = the key's fingerprint H & 0xff, 255 =
-//     several keys): a branch-free one-byte load per test -- non-survivors read slot 0, one cached line
-//     -- consumed one unit later.  That replaces the compaction of every Bloom survivor into an LDS
+//   * Survivors (12 % at 200k patterns) look their key up in a 2^24-bit map in L2 (2 MiB per combo:
+//     dword H >> 13, bit (H >> 8) & 31 -- 24 hash bits, so 1.2 % of the false survivors get through at
+//     200k keys): a branch-free dword load per test -- non-survivors read dword 0, one cached line --
+//     consumed one unit later with one SDWA shift.  That replaces the compaction of every Bloom survivor into an LDS
 //     queue and the second-level bitmap: only the ~1.3 % of the tests that are real 12-base key matches
 //     are compacted (ballot + mbcnt), probed in the bucket table and put to the q-gram test.
 // One instance per combo (pieces and displacement list are template parameters: all register indices
 // and stream offsets are immediates); the lists are edit_cover's, checked on the host at upload.
 constexpr uint32_t EDIT_MUL0 = 0x9E3779u, EDIT_MUL1 = 0xC2B2AFu, EDIT_MUL2 = 0x85EBCBu;
-constexpr int EDIT_TABLE_BITS = 21;
-constexpr int EDIT_QCAP = SEED_QCAP + SEED_Q2CAP;                  // suspicious windows per wave (8-byte entries)
+constexpr int EDIT_BUCKET = 16;                                   // slots per bucket of the second stage (64 bytes, half a cache line)
+constexpr int EDIT_QCAP = (SEED_QCAP + SEED_Q2CAP) * 2 / 3;       // suspicious windows per wave (12-byte entries)
 __device__ __host__ __forceinline__ uint32_t edit_piece_hash(uint32_t g, uint32_t mul) {
   const uint32_t y = g * mul;                                      // g < 256, mul < 2^24: no overflow
   return y ^ (y >> 16);
@@ -1009,26 +1029,50 @@ __device__ __forceinline__ uint32_t piece_hash_at(uint32_t p2, uint32_t p1, uint
 }
 typedef __attribute__((address_space(3))) uint32_t lds_w32;
 
-// the q-gram test of edits_plausible on the 2-bit packed stream (what the raw bytes pack to: same verdicts)
-__device__ __forceinline__ bool edits_plausible_packed(const SeedArgs &a, int64_t p, uint32_t pi) {
-  const int k = a.edits;
-  if (p - 21 < 0 || p + 3 > a.n) return true;
-  const uint2 pp = a.pat40[pi];
-  const uint64_t P = ((uint64_t)pp.y << 32) | pp.x;
-  const int64_t b0 = p - 21, d = b0 >> 4;
-  const uint32_t o = 2u * (uint32_t)(b0 & 15);
-  const uint32_t w0 = a.packed[d], w1 = d + 1 < a.npacked ? a.packed[d + 1] : 0u, w2 = d + 2 < a.npacked ? a.packed[d + 2] : 0u;
-  const uint32_t tl = o ? __builtin_amdgcn_alignbit(w1, w0, o) : w0, th = o ? __builtin_amdgcn_alignbit(w2, w1, o) : w1;
-  const uint64_t T = ((uint64_t)th << 32) | tl;                    // stream p-21 .. p+2 (the low 48 bits)
-  uint64_t M = 0;
-#pragma unroll
-  for (int dd = -2; dd <= 2; ++dd) {
-    if (dd < -k || dd > k) continue;
-    const uint64_t x = (P ^ (T >> (2 * (2 + dd)))) & 0xffffffffffull;
-    const uint64_t z = x | (x >> 2) | (x >> 4) | (x >> 6);
-    M |= ~(z | (z >> 1));
+// Second stage of pm_edit_scan.  A suspicious window is a 12-base key match with one of the patterns
+// (1.2 % of the tests at 200k patterns), so this path is kept to ONE cache line per window: the queue
+// entry carries the 24 stream bases around the window (no stream re-read), the bucket slot carries the
+// pattern's other two pieces next to a 16-bit fingerprint (the key pieces are the window's own: no
+// pattern load), and the q-gram test runs on registers.  The pattern index sits in a parallel table
+// that only the windows that pass read.  Bucket = 16 slots of (other pieces << 16 | fingerprint), 64 bytes.
+__device__ __forceinline__ uint32_t edit_fp16(uint32_t h2) { const uint32_t f = h2 & 0xffffu; return f == 0xffffu ? 0xfffeu : f; }
+// pattern bytes (pieces 0..3 in plo, piece 4 in bits 0..7 of p4) from the merged window and a slot's other pieces
+__device__ __forceinline__ void edit_pattern_of(uint32_t wlo, uint32_t whi, uint32_t other, uint32_t sel, uint32_t *plo, uint32_t *p4) {
+  const int qa = sel & 0xff, qb = (sel >> 8) & 0xff, qc = (sel >> 16) & 0xff;
+  uint32_t pl = 0, ph = 0;
+  int t = 0;
+  for (int q = 0; q < 5; ++q) {
+    const bool key = q == qa || q == qb || q == qc;
+    const uint32_t by = key ? (q < 4 ? (wlo >> (8 * q)) & 0xffu : whi & 0xffu) : (other >> (8 * t)) & 0xffu;
+    if (!key) ++t;
+    if (q < 4) pl |= by << (8 * q); else ph = by;
   }
-  return (int)__popcll(M & 0x155555555ull) >= 17 - 4 * k;
+  *plo = pl; *p4 = ph;
+}
+// rare (1e-3 of the suspicious windows): a full bucket -- the probe sequence goes on in the next one
+__device__ __noinline__ void edit_rare(const SeedArgs *ap, int combo, uint32_t h2, uint32_t wlo, uint32_t whi, uint32_t tl, uint32_t th, int64_t p) {
+  const SeedArgs &a = *ap;
+  const size_t nb = (size_t)1 << (32 - a.bucket_shift);
+  const uint32_t *slots = reinterpret_cast<const uint32_t *>(a.buckets) + (size_t)combo * nb * EDIT_BUCKET;
+  const uint32_t *eidx = a.eidx + (size_t)combo * nb * EDIT_BUCKET;
+  const uint32_t fp = edit_fp16(h2);
+  uint32_t b = (h2 >> a.bucket_shift) + 1;
+  for (;;) {
+    b &= (uint32_t)(nb - 1);
+    for (int q = 0; q < EDIT_BUCKET; ++q) {
+      const uint32_t sv = slots[(size_t)b * EDIT_BUCKET + q];
+      if (sv == EMPTY) return;
+      if ((sv & 0xffffu) != fp) continue;
+      uint32_t plo, p4;
+      edit_pattern_of(wlo, whi, sv >> 16, a.perm_sel[combo], &plo, &p4);
+      const bool ends = p - 21 < 0 || p + 3 > a.n;
+      if (ends || qgram_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits)) {
+        const unsigned long long o = atomicAdd(a.counter, 1ull);
+        if (o < a.cap) a.seed_out[o] = edit_seed_record(p, eidx[(size_t)b * EDIT_BUCKET + q]);
+      }
+    }
+    ++b;
+  }
 }
 
 template <int QA, int QB, int QC, uint32_t EVAR>
@@ -1036,10 +1080,19 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
   constexpr EditVariants VL = edit_variants(EVAR);
   constexpr int NV = VL.n, LOA = VL.lo_a, HIA = VL.hi_a, LOB = VL.lo_b, HIB = VL.hi_b;
   constexpr int NA = 8 + HIA - LOA, NB = 8 + HIB - LOB;
-  static_assert(NV >= 1 && QA < QB && QB < QC && QC <= 4 && QB <= 3, "combo");
+  static_assert(NV >= 1 && NV <= 10 && QA < QB && QB < QC && QC <= 4 && QB <= 3, "combo");
+  // the two pieces that are not in the key, and the byte selector that puts a slot's copy of them between the key pieces
+  constexpr int O1 = QA != 0 ? 0 : (QB != 1 ? 1 : (QC != 2 ? 2 : 3));
+  constexpr int O2 = QC != 4 ? 4 : (QB != 3 ? 3 : (QA != 2 ? 2 : 1));
+  static_assert(O1 < O2 && O1 != QA && O1 != QB && O1 != QC && O2 != QA && O2 != QB && O2 != QC, "other pieces");
+  constexpr uint32_t PSEL = (uint32_t)(0 == O1 ? 4 : (0 == O2 ? 5 : 0)) | ((uint32_t)(1 == O1 ? 4 : (1 == O2 ? 5 : 1)) << 8) |
+                            ((uint32_t)(2 == O1 ? 4 : (2 == O2 ? 5 : 2)) << 16) | ((uint32_t)(3 == O1 ? 4 : (3 == O2 ? 5 : 3)) << 24);
+  // per displacement pattern: stream bit offsets of the first and second piece's source window, 2 (s + 2), three bits each
+  constexpr uint64_t VCODE = [] { uint64_t c = 0; for (int v = 0; v < VL.n; ++v) c |= (uint64_t)((VL.sa[v] + 2) | ((VL.sb[v] + 2) << 3)) << (6 * v); return c; }();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint2 *queue = reinterpret_cast<uint2 *>(lds + SEED_BLOOM_STRIDE) + wave * EDIT_QCAP;
+  // the wave's queue of suspicious windows: {stream bases p-21 .. p-6, bases p-5 .. p+2, position | pattern << 20}
+  uint32_t *q_tl = lds + SEED_BLOOM_STRIDE + wave * (3 * EDIT_QCAP), *q_th = q_tl + EDIT_QCAP, *q_pv = q_th + EDIT_QCAP;
   const int64_t sub = a.chunk_len / WAVES;
   const int64_t ws = (a.chunk0 + cj) * a.chunk_len + (int64_t)wave * sub;
   // p = last base of the 20-base window; a candidate end e comes from seeds at p = e-1+-k
@@ -1051,11 +1104,13 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
   if (own_lo < 19) own_lo = 19;
   if (own_lo >= own_hi) return;
 
-  const uint32_t mlo = a.mask_lo[combo], mhi = a.mask_hi[combo], sel = a.perm_sel[combo];
+  const uint32_t sel = a.perm_sel[combo];
   const uint32_t ema = a.emask_a[combo], emb = a.emask_b[combo];
-  const uint4 *buckets = a.buckets + (size_t)combo * 2 * ((size_t)1 << (32 - a.bucket_shift));
-  const uint8_t *etable = a.etable + ((size_t)combo << EDIT_TABLE_BITS);
-  const uint32_t imask = (1u << a.idx_bits) - 1u;
+  const size_t nbs = (size_t)EDIT_BUCKET << (32 - a.bucket_shift);
+  const uint4 *buckets = a.buckets + (size_t)combo * (nbs / 4);
+  const uint32_t *eidx = a.eidx + (size_t)combo * nbs;
+  const uint8_t *etable = a.etable + ((size_t)combo << a.et_bytes_log);
+  const int jshift = a.et_shift;
   uint32_t carry1, carry2;
   {
     const uint32_t pk = load_packed<false>(a.packed, a.npacked, ws - 32 + 16 * (lane & 1));
@@ -1065,7 +1120,7 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
   int qn = 0;                                                     // wave-uniform queue fill
   unsigned long long ob_next = 0;                                 // seed records go to slots reserved SEED_OUT_BLOCK at a time
   int ob_left = 0;
-  auto emit = [&](bool pass, int64_t p, uint32_t pi) __attribute__((always_inline)) {
+  auto emit = [&](bool pass, int64_t p, uint32_t slot_at) __attribute__((always_inline)) {
     const unsigned long long bal = __ballot(pass);
     if (bal == 0) return;
     const int c = __popcll(bal);
@@ -1079,7 +1134,7 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
     }
     if (pass) {
       const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, pi);
+      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, eidx[slot_at]);   // the pattern index: read by the few that get here
     }
     ob_next += c; ob_left -= c;
   };
@@ -1090,53 +1145,74 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
       qn -= cnt;
       if (a.debug & 2) continue;
       const bool on = lane < cnt;
-      uint32_t h2 = 0, mm = 0, pidx = 0;
+      uint32_t h2 = 0, tl = 0, th = 0, wlo = 0, whi = 0, slot_at = 0;
       int64_t p = 0;
-      uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
-      uint2 e = make_uint2(0, 0);
-      if (on) {
-        e = queue[qn + lane];
-        p = ws + (e.y >> 8);
-        h2 = window_hash<1>(e.x, e.y & 0xffu, mlo, mhi, sel) * HASH_SLOT;
-        const size_t b = h2 >> a.bucket_shift;
-        b0 = buckets[2 * b]; b1 = buckets[2 * b + 1];
-        mm = match_mask(b0, b1, h2 << a.idx_bits, imask);
-      }
-      const uint32_t sl[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      if (mm & 255u) {
-        const int sidx = __ffs(mm) - 1;
-        uint32_t slot = 0;
+      uint4 bq[EDIT_BUCKET / 4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
-        pidx = slot & imask;
+      for (int t = 0; t < EDIT_BUCKET / 4; ++t) bq[t] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+      if (on) {
+        tl = q_tl[qn + lane]; th = q_th[qn + lane];
+        const uint32_t pv = q_pv[qn + lane];
+        p = ws + (pv & 0xfffffu);
+        // the window (stream bases p-19 .. p) with the key's first and second piece taken from where the pattern displaces them
+        const uint32_t c6 = (uint32_t)(VCODE >> (6 * (pv >> 20))) & 63u;
+        wlo = __builtin_amdgcn_alignbit(th, tl, 4); whi = (th >> 4) & 0xffu;
+        const uint32_t wa = __builtin_amdgcn_alignbit(th, tl, 2 * (c6 & 7u)), wb = __builtin_amdgcn_alignbit(th, tl, 2 * (c6 >> 3));
+        wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
+        h2 = window_hash<1>(wlo, whi, 0, 0, sel) * HASH_SLOT;
+        const size_t b = h2 >> a.bucket_shift;
+#pragma unroll
+        for (int t = 0; t < EDIT_BUCKET / 4; ++t) bq[t] = buckets[(EDIT_BUCKET / 4) * b + t];
+        slot_at = (uint32_t)b * EDIT_BUCKET;
       }
-      bool pass = false;
-      if ((mm & 255u) && !(a.debug & 4)) pass = edits_plausible_packed(a, p, pidx);
-      emit(pass, p, pidx);
-      if ((mm & 511u) && !(a.debug & 4)) {
-        uint32_t rest = (mm & 255u) & ((mm & 255u) - 1u);           // matches beyond the first (rare)
-        while (rest) {
+      uint32_t sl[EDIT_BUCKET];
+#pragma unroll
+      for (int t = 0; t < EDIT_BUCKET / 4; ++t) { sl[4 * t] = bq[t].x; sl[4 * t + 1] = bq[t].y; sl[4 * t + 2] = bq[t].z; sl[4 * t + 3] = bq[t].w; }
+      // slots fill up in order and an empty slot's low half (0xffff) is no fingerprint: no "first empty slot" bookkeeping
+      const uint32_t fp = edit_fp16(h2);
+      uint32_t mm = 0;                                               // slots whose fingerprint matches
+#pragma unroll
+      for (int t = 0; t < EDIT_BUCKET; ++t) mm |= (sl[t] & 0xffffu) == fp ? 1u << t : 0u;
+      const bool full = on && sl[EDIT_BUCKET - 1] != EMPTY && !(a.debug & 4);
+      if (!on || (a.debug & 4)) mm = 0;
+      const bool ends = p - 21 < 0 || p + 3 > a.n;                   // stream ends: the automaton decides
+      // first match: seed records in reserved blocks; further ones (two patterns with the same twelve bases) one by one
+      uint32_t rest = mm;
+      bool first = true;
+      while (__ballot(rest != 0)) {
+        bool pass = false;
+        uint32_t at = slot_at;
+        if (rest) {
           const int sidx = __ffs(rest) - 1;
           rest &= rest - 1;
-          uint32_t slot = 0;
+          uint32_t sv = 0;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) slot = sidx == t ? sl[t] : slot;
-          verify_edits(a.self, p, slot & imask);
+          for (int t = 0; t < EDIT_BUCKET; ++t) sv = sidx == t ? sl[t] : sv;
+          at += (uint32_t)sidx;
+          const uint32_t plo = __builtin_amdgcn_perm(sv >> 16, wlo, PSEL);
+          const uint32_t p4 = QC == 4 ? whi : sv >> 24;
+          pass = ends || qgram_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits);
         }
-        if (mm & 256u) probe_from<false, true>(a.self, buckets, (h2 >> a.bucket_shift) + 1, h2 << a.idx_bits, imask, mlo, mhi, ((uint64_t)(e.y & 0xffu) << 32) | e.x, p);
+        if (first) { emit(pass, p, at); first = false; }
+        else if (pass) {
+          const unsigned long long o = atomicAdd(a.counter, 1ull);
+          if (o < a.cap) a.seed_out[o] = edit_seed_record(p, eidx[at]);
+        }
       }
+      if (full) edit_rare(a.self, combo, h2, wlo, whi, tl, th, p);
     }
   };
 
+  // one block beyond the wave's range is loaded too: the last windows' q-gram tests look two bases ahead
   uint32_t q0 = load_packed<false>(a.packed, a.npacked, ws + 16 * lane);
-  uint32_t q1 = ws + 1024 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 1024 + 16 * lane) : 0u;
-  uint32_t q2 = ws + 2048 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
-  uint32_t q3 = ws + 3072 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
-  const uint32_t mul0 = EDIT_MUL0, mul1 = EDIT_MUL1, mul2 = EDIT_MUL2;
+  uint32_t q1 = load_packed<false>(a.packed, a.npacked, ws + 1024 + 16 * lane);
+  uint32_t q2 = ws + 1024 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
+  uint32_t q3 = ws + 2048 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
+  const uint32_t mul0 = EDIT_MUL0, mul1 = EDIT_MUL1, mul2 = EDIT_MUL2, tmask = a.et_mask;
   for (int64_t bb = ws; bb < own_hi; bb += 1024) {
     const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
-    if (bb + 4096 < own_hi) q3 = load_packed<false>(a.packed, a.npacked, bb + 4096 + 16 * lane);
+    if (bb + 3072 < own_hi) q3 = load_packed<false>(a.packed, a.npacked, bb + 4096 + 16 * lane);
     const uint32_t prev1 = __builtin_amdgcn_update_dpp(carry1, cur, 0x138, 0xf, 0xf, false);       // wave_shr:1
     const uint32_t prev2 = __builtin_amdgcn_update_dpp(carry2, prev1, 0x138, 0xf, 0xf, false);
     carry2 = __builtin_amdgcn_readlane(cur, 62);
@@ -1170,20 +1246,18 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
       });
 
       uint32_t Hb[2][8], Eb[2][8], surv[2] = {0, 0};
-      // consume stage of a unit: its table bytes have landed.  Suspicious = the byte equals the key's
-      // fingerprint, or says "several keys" (255); the sign of t funnels into sacc
+      // consume stage of a unit: its table dwords have landed.  Suspicious = the key's bit is set
       auto consume = [&](auto PP) __attribute__((always_inline)) -> uint32_t {
         constexpr int P = decltype(PP)::value;
         uint32_t sacc = 0;
         static_for<8>([&](auto J) __attribute__((always_inline)) {
           constexpr int j = decltype(J)::value;
-          uint32_t x;
-          asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(x) : "v"(Eb[P][j]), "v"(Hb[P][j]));
-          const uint32_t t = (x - 1u) | ((Eb[P][j] << 23) + 0x800000u);
+          uint32_t t;
+          asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t) : "v"(Hb[P][j]), "v"(Eb[P][j]));
           uint32_t &sr = sacc;
-          asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(sr) : "v"(t));   // (volatile: stays here, see the test stage)
+          asm volatile("v_alignbit_b32 %0, %1, %0, 1" : "+v"(sr) : "v"(t));   // (volatile: stays here, see the test stage)
         });
-        return (__brev(sacc) >> 24) & surv[P] & ((own >> (8 * HALF)) & 0xffu);
+        return (sacc >> 24) & surv[P] & ((own >> (8 * HALF)) & 0xffu);
       };
       static_for<NV>([&](auto VV) __attribute__((always_inline)) {
         constexpr int V = decltype(VV)::value, P = V & 1;
@@ -1199,7 +1273,7 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
         uint32_t acc = 0;
         static_for<8>([&](auto J) __attribute__((always_inline)) {
           constexpr int j = decltype(J)::value;
-          const uint32_t H = Hb[P][j], Jx = H >> 11;
+          const uint32_t H = Hb[P][j], Jx = H >> jshift;
           uint32_t s1, s2, s3;
           asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(s1) : "v"(H), "v"(wd[j]));
           asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(s2) : "v"(H), "v"(wd[j]));
@@ -1207,8 +1281,9 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
           const uint32_t v = s1 & s2 & s3;
           // (volatile: the funnel stays here -- left to the scheduler it sinks to the consume stage and the eight verdicts are spilled)
           asm volatile("v_alignbit_b32 %0, %1, %0, 1" : "+v"(acc) : "v"(v));
-          const uint32_t off = Jx & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1);   // the key's slot for a survivor, slot 0 otherwise
-          Eb[P][j] = etable[off];
+          // the key's dword for a survivor, dword 0 otherwise (three-way AND)
+          const uint32_t off = __builtin_amdgcn_bitop3_b32(Jx, (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1), tmask, 0x80);
+          Eb[P][j] = *reinterpret_cast<const uint32_t *>(etable + off);
         });
         surv[P] = acc >> 24;
         if constexpr (V > 0) sus[V - 1] |= consume(std::integral_constant<int, P ^ 1>{}) << (8 * HALF);
@@ -1218,13 +1293,14 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
 
     // compaction of the suspicious windows, one per lane and round (ballot + mbcnt give the queue slots)
     if (!(a.debug & 1)) {
+      // the dword behind the lane's own (lane 63: the next block's first) -- a window's 24 bases reach two beyond it
+      const uint32_t next = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readfirstlane(q0), cur, 0x130, 0xf, 0xf, false);   // wave_shl:1
 #pragma unroll 1
       for (int v = 0; v < NV; ++v) {
         uint32_t rem = 0;
-        int sa = 0, sb = 0;
         static_for<NV>([&](auto T) __attribute__((always_inline)) {
           constexpr int t = decltype(T)::value;
-          if (v == t) { rem = sus[t]; sa = VL.sa[t]; sb = VL.sb[t]; }
+          if (v == t) rem = sus[t];
         });
         for (;;) {
           const unsigned long long bal = __ballot(rem != 0);
@@ -1234,19 +1310,13 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
             const int i = __ffs(rem) - 1;
             __builtin_assume(i >= 0 && i < 16);
             rem &= rem - 1;
-            const int sft = 2 * i + 26;
+            const int sft = 2 * i + 22;                              // base p-21 of window i in prev2 : prev1 : cur : next
             const uint32_t x0 = __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = __builtin_amdgcn_alignbit(cur, prev1, sft),
-                           x2 = cur >> (sft & 31);
-            uint32_t wlo = sft < 32 ? x0 : x1;
-            const uint32_t whi = sft < 32 ? x1 : x2;
-            if (sa | sb) {                                         // wave-uniform
-              const int fa = sft + 2 * sa, fb = sft + 2 * sb;
-              const uint32_t wa = fa < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, fa) : __builtin_amdgcn_alignbit(cur, prev1, fa);
-              const uint32_t wb = fb < 32 ? __builtin_amdgcn_alignbit(prev1, prev2, fb) : __builtin_amdgcn_alignbit(cur, prev1, fb);
-              wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
-            }
+                           x2 = __builtin_amdgcn_alignbit(next, cur, sft);
             const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-            queue[slot] = make_uint2(wlo, (whi & 0xffu) | ((uint32_t)(pbase + i - ws) << 8));
+            q_tl[slot] = sft < 32 ? x0 : x1;
+            q_th[slot] = (sft < 32 ? x1 : x2) & 0xffffu;
+            q_pv[slot] = (uint32_t)(pbase + i - ws) | ((uint32_t)v << 20);
           }
           qn += __popcll(bal);
         }
@@ -1603,22 +1673,29 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   // buckets of 8 slots, average fill <= 3; slot = fingerprint (high bits) | pattern index (low idx_bits)
   int idx_bits = 1;
   while (((size_t)1 << idx_bits) <= np) ++idx_bits;
+  const bool edit_bloom_v1 = edits && getenv("PM_EDIT_SCAN") && !strcmp(getenv("PM_EDIT_SCAN"), "bloom");
+  const bool tabulated = edits && !edit_bloom_v1;  // first stage pm_edit_scan: 64-byte buckets of 16 slots (a full bucket is then a 1e-3 event)
+  const size_t bslots = tabulated ? EDIT_BUCKET : 8;
   size_t nbuckets = 256;
-  while (nbuckets * 3 < np) nbuckets <<= 1;
+  while (nbuckets * (tabulated ? 6 : 3) < np) nbuckets <<= 1;
   int lb = 0;
   while (((size_t)1 << lb) < nbuckets) ++lb;
   t.idx_bits = idx_bits; t.bucket_shift = 32 - lb;
-  const size_t nslots = nbuckets * 8;
+  const size_t nslots = nbuckets * bslots;
   t.nslots = nslots;
   t.bloom.assign((size_t)C * SEED_BLOOM_STRIDE, 0);
   int lb2 = 16;
   while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2;
   if (edits) lb2 = 5;                              // pm_edit_scan has its byte table instead (the older first stage builds the bitmap on request)
-  const bool edit_bloom_v1 = edits && getenv("PM_EDIT_SCAN") && !strcmp(getenv("PM_EDIT_SCAN"), "bloom");
   if (edit_bloom_v1) { lb2 = 16; while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2; }
   t.lb2 = lb2;
   t.bitmap2.assign((size_t)C << (lb2 - 5), 0);
-  if (edits && !edit_bloom_v1) t.etable.assign((size_t)C << EDIT_TABLE_BITS, 0);
+  t.etable_log = 0;
+  if (tabulated) {
+    t.etable_log = 23;                               // 2^23 key-hash bits = 1 MiB per combo: with the 2 MiB of buckets it stays in one XCD's L2
+    if (const char *env = getenv("PM_EDIT_TABLE_LOG")) { const int v = atoi(env); if (v >= 16 && v <= 26) t.etable_log = v; }
+    t.etable.assign((size_t)C << (t.etable_log - 3), 0); t.eidx.assign((size_t)C * nslots, 0);
+  }
   t.slots.assign((size_t)C * nslots, EMPTY);
   for (int i = 0; i < 256; ++i) t.cmap[i] = 0;
   t.eos_code = -1;
@@ -1671,11 +1748,10 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
         const uint32_t H = edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][0])) & 0xffu, EDIT_MUL0) ^
                            edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][1])) & 0xffu, EDIT_MUL1) ^
                            edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][2])) & 0xffu, EDIT_MUL2);
-        t.bloom[(size_t)ci * SEED_BLOOM_STRIDE + ((H & 0x1fffcu) >> 2)] |= (1u << ((H >> 16) & 31)) | (1u << ((H >> 24) & 31)) | (1u << ((H >> 19) & 31));
-        uint8_t &slot = t.etable[((size_t)ci << EDIT_TABLE_BITS) + (H >> 11)];
-        const uint32_t fp = H & 0xffu;
-        const uint8_t want = (fp == 0 || fp == 255u) ? (uint8_t)255 : (uint8_t)fp;
-        slot = slot == 0 ? want : (slot == want ? want : (uint8_t)255);
+        const int jshift = 32 - t.etable_log + 3;         // H >> jshift = byte offset of the key's dword in the map
+        t.bloom[(size_t)ci * SEED_BLOOM_STRIDE + ((H & 0x1fffcu) >> 2)] |= (1u << ((H >> 16) & 31)) | (1u << ((H >> 24) & 31)) | (1u << ((H >> (jshift + 8)) & 31));
+        const uint32_t dw = H >> (jshift + 2), bit = (H >> 8) & 31u;
+        t.etable[((size_t)ci << (t.etable_log - 3)) + (size_t)dw * 4 + (bit >> 3)] |= (uint8_t)(1u << (bit & 7u));
       } else if (t.exact_filter) {
         const uint32_t key = wlo & mlo;                           // < 2^20 = the filter's bit count
         t.bloom[(size_t)ci * SEED_BLOOM_STRIDE + (key >> 5)] |= 1u << (key & 31u);
@@ -1692,8 +1768,20 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       uint32_t *tb = &t.slots[(size_t)ci * nslots];
       for (;;) {                                   // first bucket with a free slot; probes stop at such a bucket
         int q = 0;
-        while (q < 8 && tb[(size_t)b * 8 + q] != EMPTY) ++q;
-        if (q < 8) { tb[(size_t)b * 8 + q] = ((h2 << idx_bits) & ~imask) | (uint32_t)j; break; }
+        while (q < (int)bslots && tb[(size_t)b * bslots + q] != EMPTY) ++q;
+        if (q < (int)bslots) {
+          if (!t.etable.empty()) {                 // pm_edit_scan: the pattern's two pieces outside the key | 16-bit fingerprint; index in a table of its own
+            const uint64_t W = ((uint64_t)whi << 32) | wlo;
+            uint32_t other = 0;
+            int nt = 0;
+            for (int piece = 0; piece < 5; ++piece)
+              if (piece != t.combos[ci][0] && piece != t.combos[ci][1] && piece != t.combos[ci][2]) other |= ((uint32_t)(W >> (8 * piece)) & 0xffu) << (8 * nt++);
+            const uint32_t f = h2 & 0xffffu;
+            tb[(size_t)b * bslots + q] = (other << 16) | (f == 0xffffu ? 0xfffeu : f);
+            t.eidx[(size_t)ci * nslots + (size_t)b * bslots + q] = (uint32_t)j;
+          } else tb[(size_t)b * bslots + q] = ((h2 << idx_bits) & ~imask) | (uint32_t)j;
+          break;
+        }
         b = (b + 1) & (uint32_t)(nbuckets - 1);
       }
     }
@@ -1740,8 +1828,9 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
   d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code; d->exact_filter = t.exact_filter;
   d->edits = t.edits;
-  d->edit_tabulated = !t.etable.empty();
+  d->edit_tabulated = !t.etable.empty(); d->etable_log = t.etable_log;
   if (d->edit_tabulated && (e = up(t.etable.data(), t.etable.size(), (void **)&d->etable)) != hipSuccess) return e;
+  if (d->edit_tabulated && (e = up(t.eidx.data(), t.eidx.size() * 4, (void **)&d->eidx)) != hipSuccess) return e;
   for (int c = 0; c < d->ncombos; ++c) {              // byte masks of the combo's first and second piece (edits: displaced pieces)
     d->emask_a[c] = t.r >= 3 && t.combos[c][0] < 4 ? 0xffu << (8 * t.combos[c][0]) : 0u;
     d->emask_b[c] = t.r >= 3 && t.combos[c][1] < 4 ? 0xffu << (8 * t.combos[c][1]) : 0u;
@@ -1768,7 +1857,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
 }
 
 void seed_free(SeedDevice *d) {
-  void *ptrs[] = {d->etable, d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  void *ptrs[] = {d->etable, d->eidx, d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = SeedDevice();
 }
@@ -1807,6 +1896,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   a.packed = d_packed; a.npacked = (n + 15) / 16;
   a.chunk_len = g.seg_len; a.chunk0 = (d.edits && begin > d.edits ? begin - d.edits : (d.edits ? 0 : begin)) / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;                                                   // one run ~ one chunk per CU
+  if (d.edits && d.edit_tabulated) a.group = 128;                   // pm_edit_scan: 97.2 -> 95.6 ms (3 Gbp, 100k primers; 64: 104.6, 512: 101.7)
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
   a.debug = 0;
@@ -1821,7 +1911,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   memcpy(a.emask_a, d.emask_a, sizeof(a.emask_a)); memcpy(a.emask_b, d.emask_b, sizeof(a.emask_b)); memcpy(a.evar, d.evar, sizeof(a.evar)); a.part32 = d.part32; a.part_len = d.part_len; a.part_side = d.part_side;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
-  a.etable = nullptr; a.seed_out = nullptr;
+  a.etable = nullptr; a.eidx = nullptr; a.seed_out = nullptr; a.et_shift = 0; a.et_bytes_log = 0; a.et_mask = 0;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
   if (!d.d_args) return hipErrorInvalidValue;
   a.self = reinterpret_cast<const SeedArgs *>(d.d_args);
@@ -1835,10 +1925,10 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
     if (!es || !es->d_seeds || !es->d_seed_count) return hipErrorInvalidValue;
     SeedArgs sa = a;
     sa.seed_out = es->d_seeds; sa.counter = es->d_seed_count; sa.cap = es->seed_cap;
+    sa.etable = d.etable; sa.eidx = d.eidx; sa.et_shift = 32 - d.etable_log + 3; sa.et_mask = ((1u << (d.etable_log - 3)) - 1u) & ~3u; sa.et_bytes_log = d.etable_log - 3;
     // the rare out-of-line paths read the scan's view of the argument block
     ce = hipMemcpyAsync(d.d_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st);
     if (ce != hipSuccess) return ce;
-    sa.etable = d.etable;
     if (d.edit_tabulated) hipLaunchKernelGGL(pm_edit_scan, grid, block, SEED_LDS_BYTES, st, sa);
     else hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, sa);
     if ((ce = hipGetLastError()) != hipSuccess) return ce;
