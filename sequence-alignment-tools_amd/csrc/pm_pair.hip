@@ -369,6 +369,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t q2 = ws + 2048 < own_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
   uint32_t q3 = ws + 3072 < own_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
 
+  const uint32_t m555 = 0x555u, moff = 0x1ffffeu;                  // (v_bitop3 takes no literal: constants in SGPRs)
   // consume stage of half a block (windows 8H .. 8H+7 of the block whose stream words are v2 : v1 : vc):
   // its table entries E have landed.  Returns the suspicious windows, bit j = window 8H + j.
   auto consume = [&](auto HALF, uint32_t v2, uint32_t v1, uint32_t vc, const int32_t (&E)[8]) __attribute__((always_inline)) -> uint32_t {
@@ -390,8 +391,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const uint32_t x = (uint32_t)E[j] ^ w;
       // substitutions on the six bases, minus k + 1 (the entry's top four bits, sign-extended: -(k+1), or
       // -8 when several patterns share the key): negative = suspicious; the sign bits are funnelled
-      // into sacc (v_bcnt with accumulator, v_alignbit: no compare)
-      const int z = __popc((x | (x >> 1)) & 0x555u) + (E[j] >> 12);
+      // into sacc (v_bitop3 (a | b) & c, v_bcnt with accumulator, v_alignbit: no compare)
+      const int z = __popc(__builtin_amdgcn_bitop3_b32(x, x >> 1, m555, 0xa8)) + (E[j] >> 12);
       sacc = __builtin_amdgcn_alignbit(sacc, (uint32_t)z, 31);
     }
     return __brev(sacc) >> 24;
@@ -449,7 +450,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const uint32_t v = wd[j] >> ((ks[j] >> 17) & 31u);            // bits 15..19 of the key pick the bit
       acc = __builtin_amdgcn_alignbit(v, acc, 1);
       // table index = key for a survivor, 0 otherwise (byte offset 2 * key from the key at bits 2..21)
-      const uint32_t off = (ks[j] >> 1) & 0x1ffffeu & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1);
+      const uint32_t off = __builtin_amdgcn_bitop3_b32(ks[j] >> 1, (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1), moff, 0x80);   // three-way AND
       E[j] = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(direct) + off);   // plain load: nontemporal ran 3x, sc1 1.7x slower
     }
   };
