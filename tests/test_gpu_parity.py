@@ -520,6 +520,39 @@ def test_edit_distance_seed_plan(seed):
     assert total > 0
 
 
+@pytest.mark.parametrize("env", [{"PM_EDIT_SCAN": "bloom"}, {"PM_EDIT_TABLE_LOG": "16"}, {"PM_EDIT_TABLE_LOG": "26"},
+                                 {"PM_SEED_CHUNK": "16384", "PM_SEED_GROUP": "3"}, {"PM_SEED_CHUNK": "2097152"}])
+def test_edit_distance_plan_switches(env, monkeypatch):
+    """The edit-distance plan's first stage under its switches: the round-1 form (Bloom survivors compacted,
+    PM_EDIT_SCAN=bloom), pm_edit_scan with a tiny and a huge key map (2^16 bits: nearly every Bloom survivor is
+    suspicious; 2^26), small chunks with runs of three per combo, 2 Mi chunks.  Thousands of decoy patterns fill the
+    filters and the buckets (full 16-slot buckets, several patterns with the same twelve bases); same candidates
+    and hits as the oracle (shift_and_inexact.cc:249-352, filter_bitvec.cc:88-177)."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng(4242)
+    ents = synth.make_entries(rng, 4, 6000, n_runs=2, repeats=True, short=True)
+    pats = [p for p in synth.make_patterns(rng, ents, 150, length=22, planted=0.9, indel_frac=0.6, extras=False) if 20 <= len(p) <= 32 and set(p) <= set("ACGT")]
+    base = pats[0]
+    pats += [base[:-12] + "".join(rng.choice(list("ACGT"), size=12).tolist()) for _ in range(40)]      # shared leading bases
+    pats += ["".join(rng.choice(list("ACGT"), size=10).tolist()) + base[-12:] for _ in range(40)]       # the same last twelve bases: one key, many patterns
+    pats += ["".join(rng.choice(list("ACGT"), size=21).tolist()) for _ in range(3000)]                  # decoys
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    for k, sem in ((2, sat_amd.SEM_SHIFT_AND_INEXACT), (2, sat_amd.SEM_FILTER_BITVEC), (1, sat_amd.SEM_SHIFT_AND_INEXACT)):
+        want = O.sorted_tuples(O.find_all(text, pats, engine=sem, k=k, indels=True))
+        pm = sat_amd.PatternMatch(k=k, indels=True, semantics=sem, kernel=sat_amd.KERNEL_SEED)
+        for i, p in enumerate(pats):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        assert pm.selected() == (sem, sat_amd.KERNEL_SEED)
+        got = sat_amd.sorted_tuples(pm.find_all())
+        pm.close()
+        assert len(want) > 50
+        assert got == want, (env, k, sem, len(got), len(want))
+
+
 def test_edit_distance_device_text_with_repeat_clusters():
     """Stream only in HBM (pm_init_device) + tandem repeats: the long repeat clusters that
     pm_cluster_dp hands back go through the host stage, whose window gather must not disturb the
