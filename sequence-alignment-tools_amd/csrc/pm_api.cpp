@@ -792,7 +792,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     begin = begin > reach ? begin - reach : 0;
     end = std::min<int64_t>(h->n, end + reach);
   }
-  if (h->kern == PM_KERNEL_SEED && h->edits_dev)
+  if (h->kern == PM_KERNEL_SEED && (h->edits_dev || (h->halves_dev && h->sd.half_ranked)))
   {
     // per pattern tile: scan kernel -> seed records in d_ext, verify kernel -> candidates in d_cands
     // ~1 seed record per 8 bases at 200k patterns (key matches that pass the four-base-word test)
@@ -1039,11 +1039,11 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
       return fail(h, PM_E_OVERFLOW, "suspect buffer was too small; it has been enlarged, scan the range again");
     }
   }
-  if (h->edits_dev) {
+  if (h->edits_dev || (h->halves_dev && h->sd.half_ranked)) {
     // the seed buffer of a tile must have held all its seed records
     unsigned long long worst = 0;
     for (int t = 0; t < 1 + (int)h->sd_more.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] edits: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", worst, h->seed_cap, cnt);
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] %s: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", h->edits_dev ? "edits" : "halves", worst, h->seed_cap, cnt);
     if (worst > h->seed_cap) {                                     // grow the seed buffer and tell the caller to scan again
       (void)hipFree(h->d_seeds); h->d_seeds = nullptr;
       h->seed_cap = (size_t)worst + (size_t)worst / 8 + 1024;
@@ -1051,6 +1051,8 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
       if (n_out) *n_out = h->cap + 1;                                // "> cap": pm_scan's retry condition
       return fail(h, PM_E_OVERFLOW, "seed buffer was too small; it has been enlarged, scan the range again");
     }
+  }
+  if (h->edits_dev) {
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
     if (h->scan_begin == 0 && !h->bases_edits) {                    // (exact_bases: the records are block seeds, not automaton ends)

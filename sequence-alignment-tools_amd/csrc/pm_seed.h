@@ -36,6 +36,9 @@ struct SeedTables {
   bool halves = false; int hk = 0;                // exact_halves -k mode: partner half per pattern
   int hfast = 0;                                  // see SeedArgs::hfast
   bool exact_filter = false;                      // see SeedArgs::exact_filter
+  // exact_halves -k, ranked form (pm_half_scan): key bitmap + rank directory, dense slots by rank, halves by key
+  std::vector<uint32_t> hr_image, hr_first, hr_order;
+  std::vector<uint64_t> hr_slots, hr_more;
   int edits = 0;                                  // > 0: edit-distance seed plan for this k (records in pat_codes)
   std::vector<uint8_t> etable;                    // edits: per combo, key-hash bit map of pm_edit_scan (2^etable_log bits)
   int etable_log = 0;
@@ -52,6 +55,9 @@ struct SeedDevice {
   void *pat40 = nullptr, *d_args = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr, *cmap = nullptr, *part_len = nullptr, *part_side = nullptr, *etable = nullptr;
   uint32_t *eidx = nullptr;
+  uint32_t *hr_image = nullptr, *hr_first = nullptr, *hr_order = nullptr;   // exact_halves -k: pm_half_scan / pm_half_verify tables
+  uint64_t *hr_slots = nullptr, *hr_more = nullptr;
+  bool half_ranked = false;
   int etable_log = 0;
   bool edit_tabulated = false;                    // edits: the first stage is pm_edit_scan (PM_EDIT_SCAN=bloom selects the older pm_seed_scan instance)
   uint32_t *part32 = nullptr;
@@ -73,7 +79,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
 void seed_free(SeedDevice *d);
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);
-// edit-distance plan: where the scan kernel puts its seed records (the verify kernel reads them)
+// edit-distance plan (and the ranked exact_halves -k plan): where the scan kernel puts its records (the verify kernel reads them)
 struct EditStage {
   uint64_t *d_seeds = nullptr;                    // 8-byte records: pattern index << 40 | position
   unsigned long long *d_seed_count = nullptr;     // zeroed by the caller before every launch

@@ -82,6 +82,9 @@ struct SeedArgs {
   const uint32_t *packed;               // the stream, 2 bits per base, 16 bases per dword (pack_stream); the first stage reads this
   const uint8_t *etable;                // pm_edit_scan: [combo][2^et_bytes_log bytes] bit map of the key hashes
   const uint32_t *eidx;                 // pm_edit_scan: pattern index of every bucket slot
+  const uint32_t *hr_image;             // pm_half_scan: key bitmap + rank directory (HR_IMAGE_WORDS)
+  const uint2 *hr_slots, *hr_more;      // one slot per distinct key (by rank); further halves of a key
+  const uint32_t *hr_first, *hr_order;  // pm_half_verify: halves of every key (first index by rank; pattern indices sorted by key)
   int et_shift, et_bytes_log;           // the map: H >> et_shift = byte offset of the key's dword (& et_mask), 2^et_bytes_log bytes per combo
   uint32_t et_mask;
   int64_t npacked;                      // dwords in `packed`
@@ -213,16 +216,8 @@ __device__ __forceinline__ int64_t partner_window(int64_t p, int total, int side
   return (side ? (p + 1 - total) : (p + 1)) - k;
 }
 
-__device__ __forceinline__ bool partner_possible(const SeedArgs &a, int plen, uint32_t part, uint64_t raw0, uint64_t raw1, uint64_t raw2) {
-  const int k = a.hk;
-  uint64_t T = 0;                                                   // 2 bits per base, base i of the window at bits 2i
-  const int sh = a.ascii ? 1 : 0;
-  const uint64_t raws[3] = {raw0, raw1, raw2};
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const uint32_t lo = pack4((uint32_t)raws[q], sh), hi = pack4((uint32_t)(raws[q] >> 32), sh);
-    T |= (uint64_t)(lo | (hi << 8)) << (16 * q);
-  }
+// T = the stream window from partner_window on, 2 bits per base (base i at bits 2i)
+__device__ __forceinline__ bool partner_possible_packed(int k, int plen, uint32_t part, uint64_t T) {
   // piece t of the partner = bases [t*plen/(k+1), (t+1)*plen/(k+1)); it sits unedited at displacement s
   // iff the XOR of the stream (shifted by k+s bases) with the partner is zero over the piece's bits
   auto low = [](int bases) -> uint32_t { return bases >= 16 ? 0xffffffffu : ((1u << (2 * bases)) - 1u); };
@@ -256,6 +251,18 @@ __device__ __forceinline__ bool partner_possible(const SeedArgs &a, int plen, ui
       if (((T >> (2 * (k + o + s))) & mask) == piece) return true;
   }
   return false;
+}
+
+__device__ __forceinline__ bool partner_possible(const SeedArgs &a, int plen, uint32_t part, uint64_t raw0, uint64_t raw1, uint64_t raw2) {
+  uint64_t T = 0;                                                   // 2 bits per base, base i of the window at bits 2i
+  const int sh = a.ascii ? 1 : 0;
+  const uint64_t raws[3] = {raw0, raw1, raw2};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const uint32_t lo = pack4((uint32_t)raws[q], sh), hi = pack4((uint32_t)(raws[q] >> 32), sh);
+    T |= (uint64_t)(lo | (hi << 8)) << (16 * q);
+  }
+  return partner_possible_packed(a.hk, plen, part, T);
 }
 
 // Third stage, exact part: (window ending at p, pattern pi) already passed the packed-distance
@@ -1364,6 +1371,206 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_edit_scan(SeedArgs a) {
   }
 }
 
+// ---- exact_halves -k, ranked form: pm_half_scan + pm_half_verify ------------------------------------
+//
+// A seed is an exact occurrence of a half (exact_halves.cc:199-224); at 10^5 primers 0.31 positions per
+// base end one (4^10 keys, 4e5 halves).  The HALVES instance of pm_seed_scan resolves every one of
+// them through a bucket, a 32-byte record and two raw-stream reads -- 20 MB of tables that do not fit
+// an XCD's L2, and 10^9 random 64-byte reads of the raw stream per 3 Gbp.  Here, for halves of >= 10
+// bases (patterns of >= 20):
+//   * the LDS image is the exact bitmap of the halves' last ten bases plus a rank directory (the
+//     layout of pm_pair.hip): a key hit's RANK among the set bits indexes a dense table with one 8-byte
+//     slot per distinct key -- the partner half at 2 bits per base, its length, the side it lies on;
+//     further halves with the same key (a third of the key hits) follow in a second dense table;
+//   * the queue entry carries the 48 stream bases p-31 .. p+16 (three dwords the lane has in registers),
+//     so the partner test (one of the partner's k+1 pieces unedited within k positions) runs on
+//     registers: one cache line per key hit, no stream re-read;
+//   * what passes (a few per thousand key hits) leaves as 8-byte records (rank, position); pm_half_verify
+//     walks the key's halves with the exact test on the raw stream (half_seed_ok: N and EOS reject, the
+//     half's bases in front of the key) and writes the seed records pm_seed_extend takes.
+// Halves whose partner window does not fit the 48 carried bases (patterns of 31, 32 characters) pass
+// the first kernel unfiltered.
+constexpr int HR_BITMAP_WORDS = 32768, HR_SUPER = 512, HR_REL_WORDS = 2048;
+constexpr int HR_IMAGE_WORDS = HR_BITMAP_WORDS + HR_SUPER + HR_REL_WORDS;
+constexpr int HR_QCAP = 80;                                         // key hits per wave queue (16-byte entries)
+static_assert(HR_IMAGE_WORDS * 4 + WAVES * HR_QCAP * 16 <= SEED_LDS_BYTES, "LDS");
+// slot.y: partner length (5 bits) | side << 5 | (half length - 10) << 6 | further halves with this key (3 bits, 7 = seven or more) << 9 | their first index << 12
+__device__ __host__ __forceinline__ uint32_t half_slot_info(int plen, int side, int L, uint32_t nmore, uint32_t more_at) {
+  return (uint32_t)plen | ((uint32_t)side << 5) | ((uint32_t)(L - 10) << 6) | ((nmore > 7 ? 7u : nmore) << 9) | (more_at << 12);
+}
+
+// the partner test on the carried stream bases D (base 0 = stream position p - 31); true = cannot be ruled out
+__device__ __forceinline__ bool half_partner_fast(const SeedArgs &a, uint32_t part, uint32_t info, uint32_t d0, uint32_t d1, uint32_t d2, int64_t p) {
+  const int k = a.hk;
+  const int plen = info & 31u, side = (info >> 5) & 1u, L = 10 + (int)((info >> 6) & 7u);
+  const int o = side ? 32 - L - plen - k : 32 - k;                  // first base of the partner's window (partner_window) in D
+  const int64_t r0 = p - 31 + o;
+  if (o < 0 || o + plen + 2 * k > 48 || r0 < 0 || r0 + 24 > a.n) return true;
+  const uint32_t w = (uint32_t)(2 * o) >> 5, sh = (uint32_t)(2 * o) & 31u;
+  const uint32_t a0 = w == 0 ? d0 : (w == 1 ? d1 : d2), a1 = w == 0 ? d1 : (w == 1 ? d2 : 0u), a2 = w == 0 ? d2 : 0u;
+  const uint64_t T = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
+  return partner_possible_packed(k, plen, part, T);
+}
+
+__global__ __launch_bounds__(SEED_THREADS) void pm_half_scan(SeedArgs a) {
+  extern __shared__ uint32_t lds[];
+  const int cj = blockIdx.x;
+  if (cj >= a.nchunks) return;
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.hr_image);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+    for (int i = threadIdx.x; i < HR_IMAGE_WORDS / 4; i += SEED_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t *q_d0 = lds + HR_IMAGE_WORDS + wave * (4 * HR_QCAP), *q_d1 = q_d0 + HR_QCAP, *q_d2 = q_d1 + HR_QCAP, *q_ps = q_d2 + HR_QCAP;
+  const int64_t sub = a.chunk_len / WAVES;
+  const int64_t ws = (a.chunk0 + cj) * a.chunk_len + (int64_t)wave * sub;   // p = the half's last base
+  int64_t own_lo = ws > a.begin ? ws : a.begin;
+  int64_t own_hi = ws + sub;
+  if (own_hi > a.end) own_hi = a.end;
+  if (own_hi > a.n) own_hi = a.n;
+  if (own_lo < 9) own_lo = 9;                                      // the ten key bases must fit in the stream
+  if (own_lo >= own_hi) return;
+  uint32_t carry1, carry2;
+  {
+    const uint32_t pk = load_packed<false>(a.packed, a.npacked, ws - 32 + 16 * (lane & 1));
+    carry2 = __builtin_amdgcn_readlane(pk, 0);
+    carry1 = __builtin_amdgcn_readlane(pk, 1);
+  }
+  int qn = 0;
+  unsigned long long ob_next = 0;
+  int ob_left = 0;
+  auto emit = [&](bool pass, int64_t p, uint32_t rank) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(pass);
+    if (bal == 0) return;
+    const int c = __popcll(bal);
+    if (c > ob_left) {
+      if (lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+      ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)base);
+      ob_left = SEED_OUT_BLOCK;
+    }
+    if (pass) {
+      const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, rank);
+    }
+    ob_next += c; ob_left -= c;
+  };
+  // whole batches of 64 key hits (all: what is left, too): rank -> slot -> partner test on the carried bases
+  auto process = [&](bool all) __attribute__((always_inline)) {
+    while (qn >= 64 || (all && qn > 0)) {
+      const int cnt = qn >= 64 ? 64 : qn;
+      qn -= cnt;
+      if (a.debug & 2) continue;
+      const bool on = lane < cnt;
+      uint32_t d0 = 0, d1 = 0, d2 = 0, rank = 0;
+      int64_t p = 0;
+      uint2 sv = make_uint2(0, 0);
+      if (on) {
+        d0 = q_d0[qn + lane]; d1 = q_d1[qn + lane]; d2 = q_d2[qn + lane];
+        p = ws + q_ps[qn + lane];
+        const uint32_t key = d1 >> 12;                               // bases p-9 .. p
+        // rank of the key among the set bits: superblock (2048 bits) + block (256 bits) + words + bit
+        const uint32_t word = key & 0x7fffu, bit = key >> 15;
+        const uint32_t sup = lds[HR_BITMAP_WORDS + (word >> 6)];
+        const uint32_t rel = reinterpret_cast<const uint16_t *>(lds + HR_BITMAP_WORDS + HR_SUPER)[word >> 3];
+        const u32x4 b0 = *reinterpret_cast<const u32x4 *>(lds + ((word >> 3) << 3)), b1 = *reinterpret_cast<const u32x4 *>(lds + ((word >> 3) << 3) + 4);
+        const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const uint32_t wq = word & 7u;
+        uint32_t c = sup + rel, part = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+          c += t < wq ? (uint32_t)__popc(bw[t]) : 0u;
+          part = t == wq ? bw[t] : part;
+        }
+        rank = c + __popc(__builtin_amdgcn_ubfe(part, 0, bit));
+        sv = a.hr_slots[rank];
+      }
+      bool pass = false;
+      uint32_t more = 0, at = 0;
+      if (on && !(a.debug & 4)) {
+        pass = half_partner_fast(a, sv.x, sv.y, d0, d1, d2, p);
+        more = (sv.y >> 9) & 7u; at = sv.y >> 12;
+        if (more == 7u) { pass = true; more = 0; }                   // many halves share the key: the verify kernel walks them
+        if (pass) more = 0;
+      }
+      while (__ballot(more != 0)) {                                  // further halves with the same key
+        if (more) {
+          const uint2 mv = a.hr_more[at];
+          ++at; --more;
+          if (half_partner_fast(a, mv.x, mv.y, d0, d1, d2, p)) { pass = true; more = 0; }
+        }
+      }
+      emit(pass, p, rank);
+    }
+  };
+
+  uint32_t q0 = load_packed<false>(a.packed, a.npacked, ws + 16 * lane);
+  uint32_t q1 = load_packed<false>(a.packed, a.npacked, ws + 1024 + 16 * lane);      // (one block beyond the range: the carried bases reach 16 ahead)
+  uint32_t q2 = ws + 1024 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
+  uint32_t q3 = ws + 2048 < own_hi ? load_packed<false>(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
+  for (int64_t bb = ws; bb < own_hi; bb += 1024) {
+    const uint32_t cur = q0;
+    q0 = q1; q1 = q2; q2 = q3;
+    if (bb + 3072 < own_hi) q3 = load_packed<false>(a.packed, a.npacked, bb + 4096 + 16 * lane);
+    const uint32_t prev1 = __builtin_amdgcn_update_dpp(carry1, cur, 0x138, 0xf, 0xf, false);       // wave_shr:1
+    const uint32_t prev2 = __builtin_amdgcn_update_dpp(carry2, prev1, 0x138, 0xf, 0xf, false);
+    carry2 = __builtin_amdgcn_readlane(cur, 62);
+    carry1 = __builtin_amdgcn_readlane(cur, 63);
+    const int64_t pbase = bb + 16 * lane;
+    uint32_t own = 0xffffu;
+    if (bb < own_lo || bb + 1024 > own_hi) {                       // wave-uniform: edge blocks only
+      const int64_t lo = own_lo - pbase, hi = own_hi - pbase;
+      const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
+      own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
+    }
+    // the key of window i (its last ten bases) sits at bits 2i + 46 .. 2i + 65 of prev2 : prev1 : cur
+    uint32_t acc = 0;
+    static_for<2>([&](auto HH) __attribute__((always_inline)) {
+      constexpr int HALF = decltype(HH)::value;
+      uint32_t ks[8], wd[8];
+      static_for<8>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value, i = 8 * HALF + j;
+        ks[j] = bits_at<2 * i + 44>(prev2, prev1, cur);              // the key at bits 2 .. 21
+        wd[j] = *reinterpret_cast<lds_w32 *>((uintptr_t)(ks[j] & 0x1fffcu));
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<8>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        acc = __builtin_amdgcn_alignbit(wd[j] >> ((ks[j] >> 17) & 31u), acc, 1);
+      });
+    });
+    uint32_t rem = (acc >> 16) & own;
+    if (a.debug & 1) rem = 0;
+    const uint32_t next = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readfirstlane(q0), cur, 0x130, 0xf, 0xf, false);   // wave_shl:1
+    for (;;) {
+      const unsigned long long bal = __ballot(rem != 0);
+      if (bal == 0) break;
+      const int slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+      if (rem != 0 && slot < HR_QCAP) {                              // lanes the queue has no room for keep their window for the next round
+        const int i = __ffs(rem) - 1;
+        __builtin_assume(i >= 0 && i < 16);
+        rem &= rem - 1;
+        const int sft = 2 * i + 2;                                   // stream base p - 31 in prev2 : prev1 : cur : next
+        const bool whole = sft >= 32;                                // i = 15: the three dwords as they are
+        const uint32_t x0 = whole ? prev1 : __builtin_amdgcn_alignbit(prev1, prev2, sft), x1 = whole ? cur : __builtin_amdgcn_alignbit(cur, prev1, sft),
+                       x2 = whole ? next : __builtin_amdgcn_alignbit(next, cur, sft);
+        q_d0[slot] = x0; q_d1[slot] = x1; q_d2[slot] = x2;
+        q_ps[slot] = (uint32_t)(pbase + i - ws);
+      }
+      qn += __popcll(bal);
+      if (qn > HR_QCAP) qn = HR_QCAP;
+      if (qn >= 64) process(false);                                  // whole batches from the top of the queue; fewer than 64 stay
+    }
+  }
+  process(true);
+  if (lane < ob_left && ob_next + lane < a.cap) a.seed_out[ob_next + lane] = ~0ull;
+}
+
 // Second kernel of the edit-distance plan: the seed list is dense (every lane has work), one seed
 // per lane, grid-stride; the seed count is read from device memory (no host round trip).
 struct EditVerifyArgs {
@@ -1413,6 +1620,51 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
       if (pass) {
         const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
         if (slot < a.cap) a.out[slot] = edit_record(e, pid, lvl1);
+      }
+      ob_next += c; ob_left -= c;
+    }
+  }
+  if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+}
+
+// Second kernel of the ranked exact_halves -k plan: every record (rank of a key, position) is resolved
+// into the halves that have the key; the exact test on the raw stream (half_seed_ok) decides, the seed
+// records go out in reserved blocks.
+__global__ __launch_bounds__(256) void pm_half_verify(EditVerifyArgs v) {
+  const SeedArgs &a = v.a;
+  unsigned long long n = *v.nseeds;
+  if (n > v.seed_cap) n = v.seed_cap;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long rounds = (n + stride - 1) / stride;     // same trip count for every lane: ballots stay whole-wave
+  const int lane = threadIdx.x & 63;
+  unsigned long long ob_next = 0;
+  int ob_left = 0;
+  for (unsigned long long it = 0; it < rounds; ++it) {
+    const unsigned long long i = it * stride + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t p = 0;
+    uint32_t t = 0, t1 = 0;
+    if (i < n) {
+      const uint64_t sd = v.seeds[i];
+      if (sd != ~0ull) { p = (int64_t)(sd & 0xffffffffffull); const uint32_t rank = (uint32_t)(sd >> 40); t = a.hr_first[rank]; t1 = a.hr_first[rank + 1]; }
+    }
+    while (__ballot(t < t1)) {
+      uint32_t pid = 0;
+      bool pass = false;
+      if (t < t1) { pass = half_seed_ok(a, p, a.hr_order[t], &pid); ++t; }
+      const unsigned long long bal = __ballot(pass);
+      if (bal == 0) continue;
+      const int c = __popcll(bal);
+      if (c > ob_left) {
+        if (lane < ob_left && ob_next + lane < a.cap) a.out[ob_next + lane].pid = PM_SEED_HOLE;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)SEED_OUT_BLOCK);
+        ob_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                  __builtin_amdgcn_readfirstlane((uint32_t)base);
+        ob_left = SEED_OUT_BLOCK;
+      }
+      if (pass) {
+        const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        if (slot < a.cap) a.out[slot] = half_seed_record(p, pid);
       }
       ob_next += c; ob_left -= c;
     }
@@ -1728,6 +1980,53 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       memcpy(rec + 24, &idv, 4);
     }
   }
+  // exact_halves -k, ranked form: halves of >= 10 bases, key = their last ten
+  if (partners && np > 0 && lmin >= 10 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) {
+    std::vector<uint64_t> srt(np);
+    for (size_t j = 0; j < np; ++j) {
+      const std::string &s = pats[j].s;
+      const int L = (int)s.size();
+      uint32_t key = 0;
+      for (int i = 0; i < 10; ++i) key |= (uint32_t)base2((unsigned char)s[L - 10 + i]) << (2 * i);
+      const uint32_t bitpos = ((key & 0x7fffu) << 5) | (key >> 15);   // word-major position of the key's bit (pm_pair.hip layout)
+      srt[j] = ((uint64_t)bitpos << 32) | (uint64_t)j;
+    }
+    std::sort(srt.begin(), srt.end());
+    t.hr_image.assign(HR_IMAGE_WORDS, 0);
+    t.hr_order.resize(np);
+    for (size_t j = 0; j < np;) {
+      const uint32_t bitpos = (uint32_t)(srt[j] >> 32);
+      size_t j2 = j;
+      while (j2 < np && (uint32_t)(srt[j2] >> 32) == bitpos) ++j2;
+      t.hr_image[bitpos >> 5] |= 1u << (bitpos & 31u);
+      t.hr_first.push_back((uint32_t)j);
+      const uint32_t more_at = (uint32_t)t.hr_more.size();
+      for (size_t q = j; q < j2; ++q) {
+        const uint32_t pi = (uint32_t)srt[q];
+        t.hr_order[q] = pi;
+        const uint64_t rec = (uint64_t)t.part32[pi] | ((uint64_t)half_slot_info(t.part_len[pi], t.part_side[pi], (int)pats[pi].s.size(), q == j ? (uint32_t)(j2 - j - 1) : 0u, q == j ? more_at : 0u) << 32);
+        if (q == j) t.hr_slots.push_back(rec); else t.hr_more.push_back(rec);
+      }
+      j = j2;
+    }
+    t.hr_first.push_back((uint32_t)np);
+    if (t.hr_more.size() >= ((size_t)1 << 20)) { t.hr_image.clear(); t.hr_slots.clear(); t.hr_more.clear(); t.hr_first.clear(); t.hr_order.clear(); }   // (index field of the slot: 20 bits)
+    else {
+      uint32_t *img = t.hr_image.data();
+      uint32_t *sup = img + HR_BITMAP_WORDS;
+      uint16_t *rel = reinterpret_cast<uint16_t *>(img + HR_BITMAP_WORDS + HR_SUPER);
+      uint32_t run = 0;
+      for (int sb = 0; sb < HR_SUPER; ++sb) {          // set bits before every 2048-bit superblock (u32) and, inside it, before every 256-bit block (u16)
+        sup[sb] = run;
+        uint32_t in = 0;
+        for (int b = 0; b < 8; ++b) {
+          rel[sb * 8 + b] = (uint16_t)in;
+          for (int w = 0; w < 8; ++w) in += (uint32_t)__builtin_popcount(img[sb * 64 + b * 8 + w]);
+        }
+        run += in;
+      }
+    }
+  }
   // filter, second-level bitmap and bucket table per combo: the combos' tables are disjoint, and
   // the inserts are cache misses into megabytes of table, so one thread per combo
   auto build_combo = [&](int ci) {
@@ -1827,6 +2126,14 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   if ((e = up(t.part_len.data(), t.part_len.size(), (void **)&d->part_len)) != hipSuccess) return e;
   if ((e = up(t.part_side.data(), t.part_side.size(), (void **)&d->part_side)) != hipSuccess) return e;
   d->halves = t.halves; d->hk = t.hk; d->hfast = t.hfast; d->eos_code = t.eos_code; d->exact_filter = t.exact_filter;
+  d->half_ranked = !t.hr_image.empty();
+  if (d->half_ranked) {
+    if ((e = up(t.hr_image.data(), t.hr_image.size() * 4, (void **)&d->hr_image)) != hipSuccess) return e;
+    if ((e = up(t.hr_slots.data(), t.hr_slots.size() * 8, (void **)&d->hr_slots)) != hipSuccess) return e;
+    if ((e = up(t.hr_more.data(), t.hr_more.size() * 8, (void **)&d->hr_more)) != hipSuccess) return e;
+    if ((e = up(t.hr_first.data(), t.hr_first.size() * 4, (void **)&d->hr_first)) != hipSuccess) return e;
+    if ((e = up(t.hr_order.data(), t.hr_order.size() * 4, (void **)&d->hr_order)) != hipSuccess) return e;
+  }
   d->edits = t.edits;
   d->edit_tabulated = !t.etable.empty(); d->etable_log = t.etable_log;
   if (d->edit_tabulated && (e = up(t.etable.data(), t.etable.size(), (void **)&d->etable)) != hipSuccess) return e;
@@ -1844,7 +2151,8 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
   const void *kernels[] = {reinterpret_cast<const void *>(pm_seed_scan<20, 1, false>), reinterpret_cast<const void *>(pm_seed_scan<20, 2, false>),
                            reinterpret_cast<const void *>(pm_seed_scan<20, 0, false>), reinterpret_cast<const void *>(pm_seed_scan<0, 0, false>),
                            reinterpret_cast<const void *>(pm_seed_scan<0, 0, true>),
-                           reinterpret_cast<const void *>(pm_seed_scan<20, 1, false, true>), reinterpret_cast<const void *>(pm_edit_scan)};
+                           reinterpret_cast<const void *>(pm_seed_scan<20, 1, false, true>), reinterpret_cast<const void *>(pm_edit_scan),
+                           reinterpret_cast<const void *>(pm_half_scan)};
   for (const void *kf : kernels) {
     // bloom_block addresses the filter from LDS address 0: a kernel that acquired static LDS (which
     // the dynamic block would follow) must fail here, at init, not compute with a shifted filter
@@ -1857,7 +2165,7 @@ hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st) {
 }
 
 void seed_free(SeedDevice *d) {
-  void *ptrs[] = {d->etable, d->eidx, d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
+  void *ptrs[] = {d->hr_image, d->hr_slots, d->hr_more, d->hr_first, d->hr_order, d->etable, d->eidx, d->part32, d->part_len, d->part_side, d->d_args, d->bloom, d->slots, d->bitmap2, d->pat40, d->pat_len, d->pat_id, d->pat_codes, d->cmap};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = SeedDevice();
 }
@@ -1912,6 +2220,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id;
   a.pat_codes = d.pat_codes; a.cmap = d.cmap; a.out = d_out; a.counter = d_counter; a.cap = cap;
   a.etable = nullptr; a.eidx = nullptr; a.seed_out = nullptr; a.et_shift = 0; a.et_bytes_log = 0; a.et_mask = 0;
+  a.hr_image = d.hr_image; a.hr_slots = reinterpret_cast<const uint2 *>(d.hr_slots); a.hr_more = reinterpret_cast<const uint2 *>(d.hr_more); a.hr_first = d.hr_first; a.hr_order = d.hr_order;
   // the rare out-of-line paths read their parameters from a device copy of the argument block
   if (!d.d_args) return hipErrorInvalidValue;
   a.self = reinterpret_cast<const SeedArgs *>(d.d_args);
@@ -1941,6 +2250,19 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
       hipLaunchKernelGGL(pm_bases_verify, dim3(256 * 16), dim3(256), 0, st, v, b);
     } else
     hipLaunchKernelGGL(pm_edits_verify, dim3(256 * 16), dim3(256), 0, st, v);
+  }
+  else if (d.halves && d.half_ranked) {
+    // two kernels: pm_half_scan writes (rank of the key, position) records of the key hits whose partner test passes
+    // into es->d_seeds, pm_half_verify resolves them on the raw stream into seed records.  *es->d_seed_count zeroed by the caller.
+    if (!es || !es->d_seeds || !es->d_seed_count) return hipErrorInvalidValue;
+    SeedArgs sa = a;
+    sa.seed_out = es->d_seeds; sa.counter = es->d_seed_count; sa.cap = es->seed_cap;
+    hipLaunchKernelGGL(pm_half_scan, dim3(g.nseg), block, SEED_LDS_BYTES, st, sa);
+    if ((ce = hipGetLastError()) != hipSuccess) return ce;
+    EditVerifyArgs v;
+    v.a = a;
+    v.seeds = es->d_seeds; v.nseeds = es->d_seed_count; v.seed_cap = es->seed_cap;
+    hipLaunchKernelGGL(pm_half_verify, dim3(256 * 16), dim3(256), 0, st, v);
   }
   else if (d.halves) hipLaunchKernelGGL((pm_seed_scan<0, 0, true>), grid, block, SEED_LDS_BYTES, st, a);
   else if (d.Lw == 20 && d.mode == 1) hipLaunchKernelGGL((pm_seed_scan<20, 1, false>), grid, block, SEED_LDS_BYTES, st, a);

@@ -553,6 +553,45 @@ def test_edit_distance_plan_switches(env, monkeypatch):
         assert got == want, (env, k, sem, len(got), len(want))
 
 
+@pytest.mark.parametrize("env", [{}, {"PM_HALF_SCAN": "bloom"}, {"PM_SEED_CHUNK": "16384"}])
+def test_exact_halves_edits_plans(env, monkeypatch):
+    """exact_halves -k 1 / -k 2 (exact_halves.cc:120-224: exact seeds of the halves, banded extension of the partner)
+    on the ranked plan (pm_half_scan + pm_half_verify: key bitmap + rank directory in LDS, partner test on the
+    carried stream bases) and on the round-1 form behind PM_HALF_SCAN=bloom.  Patterns of 20..32 characters -- for
+    31 and 32 the partner window does not fit the carried bases and every key hit goes to the verify kernel --, many
+    halves with the same last ten bases (more than the slot's seven), N runs, a short entry, the stream's ends."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng(777)
+    ents = synth.make_entries(rng, 4, 7000, n_runs=3, repeats=True, short=True)
+    pats = []
+    for L in (20, 21, 25, 26, 30, 31, 32):
+        pats += [p for p in synth.make_patterns(rng, ents, 40, length=L, planted=0.9, indel_frac=0.5, extras=False) if 20 <= len(p) <= 32 and set(p) <= set("ACGT")]
+    base = pats[0]
+    h = len(base) // 2
+    pats += ["".join(rng.choice(list("ACGT"), size=h - 10).tolist()) + base[h - 10:h] + "".join(rng.choice(list("ACGT"), size=len(base) - h).tolist()) for _ in range(12)]   # left halves with one key
+    pats += [base[:h] + "".join(rng.choice(list("ACGT"), size=len(base) - h - 10).tolist()) + base[-10:] for _ in range(12)]                                                   # right halves with one key
+    pats += [ents[0][:24], ents[-1][-26:]]                                  # at the stream's ends
+    pats += ["".join(rng.choice(list("ACGT"), size=22).tolist()) for _ in range(2500)]   # decoys
+    pats = [p for p in pats if set(p) <= set("ACGT") and 20 <= len(p) <= 32]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    raw = np.frombuffer(synth.stream(ents), dtype=np.uint8)
+    for stream_codes, tbl in ((codes, table), (raw, None)):
+        text = O.Text(stream_codes, tbl)
+        for k in (1, 2):
+            want = O.sorted_tuples(O.find_all(text, pats, engine=sat_amd.SEM_EXACT_HALVES, k=k, indels=True))
+            pm = sat_amd.PatternMatch(k=k, indels=True, semantics=sat_amd.SEM_EXACT_HALVES, kernel=sat_amd.KERNEL_SEED)
+            for i, p in enumerate(pats):
+                pm.add_pattern(p, i + 1)
+            pm.init(stream_codes, tbl)
+            assert pm.selected() == (sat_amd.SEM_EXACT_HALVES, sat_amd.KERNEL_SEED)
+            got = sat_amd.sorted_tuples(pm.find_all())
+            pm.close()
+            assert len(want) > 100
+            assert got == want, (env, tbl is None, k, len(got), len(want))
+
+
 def test_edit_distance_device_text_with_repeat_clusters():
     """Stream only in HBM (pm_init_device) + tandem repeats: the long repeat clusters that
     pm_cluster_dp hands back go through the host stage, whose window gather must not disturb the
