@@ -760,7 +760,8 @@ extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   }
   else if (h->kern == PM_KERNEL_SEED) {
     snprintf(buf, buflen, "kernel=%s tiles=%d combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
-             h->sd.edits && h->sd.edit_tabulated ? "pm_edit_scan+pm_edits_verify" : h->sd.edits ? "pm_seed_scan+pm_edits_verify" : "pm_seed_scan", 1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
+             h->sd.edits && h->sd.edit_tabulated ? "pm_edit_scan+pm_edits_verify" : h->sd.edits ? "pm_seed_scan+pm_edits_verify" :
+             h->sd.halves && h->sd.half_ranked ? "pm_half_scan+pm_half_verify" : "pm_seed_scan", 1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
              h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
     if (h->nrest) {
       const size_t at = strlen(buf);
