@@ -488,6 +488,31 @@ __device__ __forceinline__ bool qgram_close(uint32_t plo, uint32_t phi, uint32_t
   return (int)(__popc(mlo & 0x1555555u) + __popc(mhi & 0x154u)) >= 17 - 4 * k;
 }
 
+// The same count with three-base words (18 of them, at most 3k missing).  Twelve clean bases in a row -- the key of
+// the combos made of adjacent pieces -- hold 9 four-base words, all that qgram_close asks for at k = 2, but only 10
+// of the 12 three-base words needed: for those combos this is the test that rejects chance key matches.
+__device__ __forceinline__ bool qgram3_close(uint32_t plo, uint32_t phi, uint32_t tl, uint32_t th, int k) {
+  const uint32_t tm = __builtin_amdgcn_alignbit(th, tl, 24);
+  auto words = [](uint32_t x) __attribute__((always_inline)) -> uint32_t {   // bit 2j: the three bases from j on are equal
+    const uint32_t z = x | (x >> 2) | (x >> 4);
+    return ~(z | (z >> 1));
+  };
+  uint32_t mlo = 0, mhi = 0, pend = 0;
+  int npend = 0;
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) {
+    if (d < -k || d > k) continue;                                 // wave-uniform
+    const int c = 2 * (2 + d);
+    mlo |= words(plo ^ (c ? __builtin_amdgcn_alignbit(th, tl, c) : tl));
+    const uint32_t y = (phi ^ (tm >> c)) & 0xffffu;
+    if (npend == 0) { pend = y; npend = 1; }
+    else { mhi |= words(pend | (y << 16)); npend = 0; }
+  }
+  if (npend) mhi |= words(pend | 0xffff0000u);
+  mhi |= mhi >> 16;
+  return (int)(__popc(mlo & 0x5555555u) + __popc(mhi & 0x550u)) >= 18 - 3 * k;   // words 0..13 in the low dword, 14..17 at bits 28..39
+}
+
 __device__ __forceinline__ bool edits_plausible(const SeedArgs &a, int64_t p, uint32_t pi) {
   if (p - 21 < 0 || p + 3 > a.n) return true;                     // stream ends: let the automaton decide
   const uint2 pp = a.pat40[pi];                                   // base j of the last 20 at bits 2j
@@ -1061,7 +1086,6 @@ __device__ __noinline__ void edit_rare(const SeedArgs *ap, int combo, uint32_t h
   const SeedArgs &a = *ap;
   const size_t nb = (size_t)1 << (32 - a.bucket_shift);
   const uint32_t *slots = reinterpret_cast<const uint32_t *>(a.buckets) + (size_t)combo * nb * EDIT_BUCKET;
-  const uint32_t *eidx = a.eidx + (size_t)combo * nb * EDIT_BUCKET;
   const uint32_t fp = edit_fp16(h2);
   uint32_t b = (h2 >> a.bucket_shift) + 1;
   for (;;) {
@@ -1073,9 +1097,9 @@ __device__ __noinline__ void edit_rare(const SeedArgs *ap, int combo, uint32_t h
       uint32_t plo, p4;
       edit_pattern_of(wlo, whi, sv >> 16, a.perm_sel[combo], &plo, &p4);
       const bool ends = p - 21 < 0 || p + 3 > a.n;
-      if (ends || qgram_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits)) {
+      if (ends || (qgram_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits) && qgram3_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits))) {
         const unsigned long long o = atomicAdd(a.counter, 1ull);
-        if (o < a.cap) a.seed_out[o] = edit_seed_record(p, eidx[(size_t)b * EDIT_BUCKET + q]);
+        if (o < a.cap) a.seed_out[o] = edit_seed_record(p, ((uint32_t)combo << 20) | (uint32_t)((size_t)b * EDIT_BUCKET + q));
       }
     }
     ++b;
@@ -1115,7 +1139,6 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
   const uint32_t ema = a.emask_a[combo], emb = a.emask_b[combo];
   const size_t nbs = (size_t)EDIT_BUCKET << (32 - a.bucket_shift);
   const uint4 *buckets = a.buckets + (size_t)combo * (nbs / 4);
-  const uint32_t *eidx = a.eidx + (size_t)combo * nbs;
   const uint8_t *etable = a.etable + ((size_t)combo << a.et_bytes_log);
   const int jshift = a.et_shift;
   uint32_t carry1, carry2;
@@ -1141,7 +1164,7 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
     }
     if (pass) {
       const unsigned long long slot = ob_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, eidx[slot_at]);   // the pattern index: read by the few that get here
+      if (slot < a.cap) a.seed_out[slot] = edit_seed_record(p, ((uint32_t)combo << 20) | slot_at);   // (combo, slot): pm_edits_verify looks the pattern up
     }
     ob_next += c; ob_left -= c;
   };
@@ -1152,7 +1175,7 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
       qn -= cnt;
       if (a.debug & 2) continue;
       const bool on = lane < cnt;
-      uint32_t h2 = 0, tl = 0, th = 0, wlo = 0, whi = 0, slot_at = 0;
+      uint32_t h2 = 0, tl = 0, th = 0, wlo = 0, whi = 0, slot_at = 0, c6 = 0, wraw = 0;
       int64_t p = 0;
       uint4 bq[EDIT_BUCKET / 4];
 #pragma unroll
@@ -1162,8 +1185,9 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
         const uint32_t pv = q_pv[qn + lane];
         p = ws + (pv & 0xfffffu);
         // the window (stream bases p-19 .. p) with the key's first and second piece taken from where the pattern displaces them
-        const uint32_t c6 = (uint32_t)(VCODE >> (6 * (pv >> 20))) & 63u;
+        c6 = (uint32_t)(VCODE >> (6 * (pv >> 20))) & 63u;
         wlo = __builtin_amdgcn_alignbit(th, tl, 4); whi = (th >> 4) & 0xffu;
+        wraw = wlo;                                                  // the window as it stands in the stream
         const uint32_t wa = __builtin_amdgcn_alignbit(th, tl, 2 * (c6 & 7u)), wb = __builtin_amdgcn_alignbit(th, tl, 2 * (c6 >> 3));
         wlo = (wa & ema) | (~ema & ((wb & emb) | (~emb & wlo)));
         h2 = window_hash<1>(wlo, whi, 0, 0, sel) * HASH_SLOT;
@@ -1199,11 +1223,24 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
           const uint32_t plo = __builtin_amdgcn_perm(sv >> 16, wlo, PSEL);
           const uint32_t p4 = QC == 4 ? whi : sv >> 24;
           pass = ends || qgram_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits);
+          pass = pass && (ends || qgram3_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits));
+          // One report per (window, pattern) among the undisplaced tests: a pattern that agrees with the window on
+          // more than three pieces is found by every triple of them; the lexicographically first triple reports
+          // (every combo tests the zero displacement, and its own three pieces are among the equal ones).
+          if (pass && c6 == 18u) {
+            const uint32_t x = plo ^ wraw;
+            uint32_t eq = ((x & 0xffu) == 0 ? 1u : 0u) | ((x & 0xff00u) == 0 ? 2u : 0u) | ((x & 0xff0000u) == 0 ? 4u : 0u) | ((x >> 24) == 0 ? 8u : 0u) |
+                          (((p4 ^ whi) & 0xffu) == 0 ? 16u : 0u);
+            const uint32_t m1 = eq & (0u - eq); eq ^= m1;
+            const uint32_t m2 = eq & (0u - eq); eq ^= m2;
+            const uint32_t m3 = eq & (0u - eq);
+            pass = (m1 | m2 | m3) == ((1u << QA) | (1u << QB) | (1u << QC));
+          }
         }
         if (first) { emit(pass, p, at); first = false; }
         else if (pass) {
           const unsigned long long o = atomicAdd(a.counter, 1ull);
-          if (o < a.cap) a.seed_out[o] = edit_seed_record(p, eidx[at]);
+          if (o < a.cap) a.seed_out[o] = edit_seed_record(p, ((uint32_t)combo << 20) | at);
         }
       }
       if (full) edit_rare(a.self, combo, h2, wlo, whi, tl, th, p);
@@ -1580,6 +1617,13 @@ struct EditVerifyArgs {
   unsigned long long seed_cap;
 };
 
+// pattern of a seed record: pm_edit_scan writes (combo << 20 | bucket slot) -- the pattern index of a slot sits in a
+// table of its own (a.eidx) that the scan kernel never reads, so it does not compete for L2 with the slots; the
+// round-1 first stage writes the pattern index itself
+__device__ __forceinline__ uint32_t seed_pattern(const SeedArgs &a, uint32_t code) {
+  return a.eidx ? a.eidx[(size_t)(code >> 20) * ((size_t)EDIT_BUCKET << (32 - a.bucket_shift)) + (code & 0xfffffu)] : code;
+}
+
 __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
   const SeedArgs &a = v.a;
   unsigned long long n = *v.nseeds;
@@ -1598,7 +1642,7 @@ __global__ __launch_bounds__(256) void pm_edits_verify(EditVerifyArgs v) {
     int64_t p = 0;
     if (i < n) {
       const uint64_t sd = v.seeds[i];
-      if (sd != ~0ull) { p = (int64_t)(sd & 0xffffffffffull); res = edits_verify(a, p, (uint32_t)(sd >> 40), &pid); }
+      if (sd != ~0ull) { p = (int64_t)(sd & 0xffffffffffull); res = edits_verify(a, p, seed_pattern(a, (uint32_t)(sd >> 40)), &pid); }
     }
     if (__ballot(res != 0) == 0) continue;
 #pragma unroll 1
@@ -1711,7 +1755,7 @@ __global__ __launch_bounds__(256) void pm_bases_verify(EditVerifyArgs v, BasesAr
       if (sd != ~0ull) {
         live = true;
         p = (int64_t)(sd & 0xffffffffffull);
-        pid = a.pat_id[(uint32_t)(sd >> 40)];                        // 1-based index into the whole pattern list
+        pid = a.pat_id[seed_pattern(a, (uint32_t)(sd >> 40))];        // 1-based index into the whole pattern list
         L = b.len[pid - 1];
         const int es = b.esb[pid - 1], ee = b.eeb[pid - 1];
         prefix = es >= ee;                                           // exact_bases.cc:139-150: the larger block decides
@@ -1929,7 +1973,8 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   const bool tabulated = edits && !edit_bloom_v1;  // first stage pm_edit_scan: 64-byte buckets of 16 slots (a full bucket is then a 1e-3 event)
   const size_t bslots = tabulated ? EDIT_BUCKET : 8;
   size_t nbuckets = 256;
-  while (nbuckets * (tabulated ? 6 : 3) < np) nbuckets <<= 1;
+  // (tabulated: 200k patterns -> 32768 buckets = 2 MiB per combo; 65536 with the 1 MiB key map overflowed an XCD's 4 MiB of L2)
+  while (nbuckets * (tabulated ? 7 : 3) < np) nbuckets <<= 1;
   int lb = 0;
   while (((size_t)1 << lb) < nbuckets) ++lb;
   t.idx_bits = idx_bits; t.bucket_shift = 32 - lb;
@@ -1946,6 +1991,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   if (tabulated) {
     t.etable_log = 23;                               // 2^23 key-hash bits = 1 MiB per combo: with the 2 MiB of buckets it stays in one XCD's L2
     if (const char *env = getenv("PM_EDIT_TABLE_LOG")) { const int v = atoi(env); if (v >= 16 && v <= 26) t.etable_log = v; }
+    if (nslots > ((size_t)1 << 20)) return "pattern tile too large for the edit-distance plan's seed records (20-bit slot index)";
     t.etable.assign((size_t)C << (t.etable_log - 3), 0); t.eidx.assign((size_t)C * nslots, 0);
   }
   t.slots.assign((size_t)C * nslots, EMPTY);
@@ -2204,7 +2250,6 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   a.packed = d_packed; a.npacked = (n + 15) / 16;
   a.chunk_len = g.seg_len; a.chunk0 = (d.edits && begin > d.edits ? begin - d.edits : (d.edits ? 0 : begin)) / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;                                                   // one run ~ one chunk per CU
-  if (d.edits && d.edit_tabulated) a.group = 128;                   // pm_edit_scan: 97.2 -> 95.6 ms (3 Gbp, 100k primers; 64: 104.6, 512: 101.7)
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
   a.debug = 0;
@@ -2243,6 +2288,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
     if ((ce = hipGetLastError()) != hipSuccess) return ce;
     EditVerifyArgs v;
     v.a = a;
+    if (d.edit_tabulated) v.a.eidx = d.eidx;
     v.seeds = es->d_seeds; v.nseeds = es->d_seed_count; v.seed_cap = es->seed_cap;
     if (es->bases) {
       BasesArgs b;
