@@ -488,6 +488,9 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     // halves of <= 10 bases: the filter is the exact bitmap of their keys (SeedArgs::exact_filter) and
     // has no capacity to exceed -- one pass over the stream for all of them
     if (halves_mode && force_lw > 0 && force_lw <= 10) tile_keys = (size_t)1 << 21;
+    // halves of >= 10 bases go through the ranked plan (pm_half_scan): its key bitmap has no capacity either, and a
+    // tile of 2^20 halves keeps the "further halves of a key" index inside the slot's 20 bits
+    if (halves_mode && force_lw >= 10 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) tile_keys = (size_t)1 << 20;
     if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
     const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
     size_t per = (sp.size() + ntile - 1) / ntile;
