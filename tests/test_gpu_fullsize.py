@@ -218,6 +218,46 @@ def test_edit_distance_plants_at_scale():
     pm.close()
 
 
+@pytest.mark.parametrize("L", [20, 23])
+def test_exact_halves_edits_at_scale(L):
+    """-k 1 (exact_halves, exact_halves.cc:120-224) on 1 Gbp x 100k primers, the ranked plan (pm_half_scan +
+    pm_half_verify): primers that are database sites with 0 or 1 random edit -- one half stays exact, the other
+    is within one edit -- are reported at their site, at the start of the stream and at its far end; the
+    round-1 form behind PM_HALF_SCAN=bloom reports the same hits on a 64 Mbp prefix."""
+    n, P, k = 1 << 30, 100_000, 1
+    dev = make_db(n, 61 + L)
+    rng = np.random.default_rng(61 + L)
+    head = dev[: 1 << 24].cpu().numpy()
+    tail_at = n - (1 << 24)
+    tail = dev[tail_at:].cpu().numpy()
+    plant = [x for d in range(2) for x in plant_edits(head, rng, 200, L, d)]
+    plant += [(p_, a + tail_at, sl, d) for d in range(2) for (p_, a, sl, d) in plant_edits(tail, rng, 200, L, d)]
+    pats = [p_ for p_, _, _, _ in plant] + random_primers(rng, P - len(plant), L)
+    allp = pats + [sat_amd.reverse_comp(p_) for p_ in pats]
+    pm = engine(allp, k, sat_amd.KERNEL_AUTO, dev, indels=True)
+    assert pm.selected() == (sat_amd.SEM_EXACT_HALVES, sat_amd.KERNEL_SEED)
+    assert "pm_half_scan" in pm.describe(), pm.describe()
+    hits = pm.find_all(chunk=1 << 30)
+    key, kk = hit_index(hits)
+    for i, (_, a, sl, d) in enumerate(plant):
+        assert found(key, kk, i + 1, a + sl, 2 * k + 1 + d, d), ("planted primer not found", i, a, d)
+    pm.close()
+    # the two forms of the seed stage agree (prefix of the stream, every hit)
+    import os
+    sub = dev[: 1 << 26]
+    got = []
+    for form in ("", "bloom"):
+        if form:
+            os.environ["PM_HALF_SCAN"] = form
+        try:
+            pm = engine(allp, k, sat_amd.KERNEL_AUTO, sub, indels=True)
+            got.append(sat_amd.sorted_tuples(pm.find_all(chunk=1 << 30)))
+            pm.close()
+        finally:
+            os.environ.pop("PM_HALF_SCAN", None)
+    assert len(got[0]) > 100 and got[0] == got[1]
+
+
 def test_stream_beyond_two_to_the_32_with_default_chunks():
     """4.3e9 stream bytes (positions need more than 32 bits), -K 2 with the chunk size the library
     picks by itself for large ranges (2 Mi positions per workgroup): sites planted at the far end of
