@@ -36,7 +36,7 @@ bool is_false(const char *s) { return any_of(s, kFalse); }
 
 [[noreturn]] void usage(const char *msg) {
   if (msg && *msg) fprintf(stderr, "%s\n\n", msg);
-  fprintf(stderr, "Usage: pm_compress_seq -i <fasta> [-e bool] [-S bool] [-E int] [-u bool] [-n bool] [-D bool] [-C bool] [-F bool]\n");
+  fprintf(stderr, "Usage: pm_compress_seq -i <fasta> [-e bool] [-S bool] [-E int] [-u bool] [-n bool] [-z bool] [-D bool] [-C bool] [-F bool]\n");
   exit(1);
 }
 
@@ -59,10 +59,10 @@ void write_file(const std::string &path, const std::vector<unsigned char> &data)
 
 int main(int argc, char **argv) {
   std::string database;
-  bool eos = true, init_eos = true, uc = true, normalize = false, dnaopt = true, cleanup = true;
+  bool eos = true, init_eos = true, uc = true, normalize = false, compress = false, dnaopt = true, cleanup = true;
   char eos_char = '\n';
   int c;
-  while ((c = getopt(argc, argv, "i:e:S:u:D:E:n:F:C:h")) != -1) switch (c) {
+  while ((c = getopt(argc, argv, "i:e:S:u:D:E:n:z:F:C:h")) != -1) switch (c) {
       case 'i': database = optarg; break;
       case 'e': eos = flag("e", optarg); break;
       case 'S': init_eos = flag("S", optarg); if (init_eos) eos = true; break;     // compress_seq.cc:152-156
@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
       case 'u': uc = flag("u", optarg); break;
       case 'D': dnaopt = flag("D", optarg); break;
       case 'n': normalize = flag("n", optarg); break;
+      case 'z': compress = flag("z", optarg); break;
       case 'F': (void)flag("F", optarg); break;
       case 'C': cleanup = flag("C", optarg); break;
       default: usage(nullptr);
@@ -118,7 +119,7 @@ int main(int argc, char **argv) {
       } else {
         if (uc) ch = (char)toupper((unsigned char)ch);
         seq.push_back((unsigned char)ch); ++seqpos;
-        if (normalize) obs[(unsigned char)ch] = true;
+        if (normalize || compress) obs[(unsigned char)ch] = true;      // compress_seq.cc:565
         startofline = false;
       }
     }
@@ -140,7 +141,7 @@ int main(int argc, char **argv) {
     memcpy(idb.data() + 8, idx.data(), idx.size() * 8);
     write_file(database + ".idb", idb);
   }
-  if (!normalize) return 0;
+  if (!normalize && !compress) return 0;
 
   int order[256];
   for (int i = 0; i < 256; ++i) order[i] = i;
@@ -153,10 +154,36 @@ int main(int argc, char **argv) {
   memset(inv, 255, sizeof(inv));
   for (int i = 0; i < 256; ++i)
     if (obs[order[i]]) { inv[order[i]] = (unsigned char)tbl.size(); tbl.push_back((unsigned char)order[i]); }
-  write_file(database + ".tbl", tbl);
-  std::vector<unsigned char> sqn(seq.size());
-  for (size_t i = 0; i < seq.size(); ++i) sqn[i] = inv[seq[i]];
-  write_file(database + ".sqn", sqn);
+  if (normalize) write_file(database + ".tbl", tbl);
+  if (compress) {
+    // <db>.tbz (the same table) + <db>.sqz: the codes at ceil(log2(table size)) bits each, most significant bit
+    // first, the last buffer of lcm(bits, 8) bytes filled up with end-of-sequence codes (compress_seq.cc:741-905)
+    write_file(database + ".tbz", tbl);
+    unsigned bits = 1;
+    while ((1u << bits) < tbl.size()) ++bits;
+    size_t lcm = bits;
+    while (lcm % 8) lcm += bits;
+    const size_t bufbits = lcm * 8;                       // bufsize = lcm(bits, 8) / 8 * 8 bytes
+    if (inv[(unsigned char)eos_char] == 255 && !seq.empty() && (seq.size() * bits) % bufbits) {
+      fprintf(stderr, "The end-of-sequence character is not in the table: cannot fill up %s.sqz\n", database.c_str());
+      return 1;
+    }
+    size_t nchars = seq.size();
+    while ((nchars * bits) % bufbits) ++nchars;
+    std::vector<unsigned char> sqz(nchars * bits / 8, 0);
+    size_t bitat = 0;
+    for (size_t i = 0; i < nchars; ++i) {
+      const unsigned code = i < seq.size() ? inv[seq[i]] : inv[(unsigned char)eos_char];
+      for (int b = (int)bits - 1; b >= 0; --b, ++bitat)
+        if ((code >> b) & 1u) sqz[bitat >> 3] |= (unsigned char)(0x80u >> (bitat & 7));
+    }
+    write_file(database + ".sqz", sqz);
+  }
+  if (normalize) {
+    std::vector<unsigned char> sqn(seq.size());
+    for (size_t i = 0; i < seq.size(); ++i) sqn[i] = inv[seq[i]];
+    write_file(database + ".sqn", sqn);
+  }
   if (cleanup) unlink((database + ".seq").c_str());
   return 0;
 }

@@ -99,11 +99,30 @@ SeqDb::SeqDb(const std::string &database, int format, bool load_headers, bool ch
     if (!load(database + ".sqn") || !read_file(database + ".tbl", &tb))
       die(("Can't open normalized sequence database " + database + ".sqn/.tbl").c_str());
     table_.assign(tb.begin(), tb.end());
+  } else if ((format == 0 && file_exists(database + ".sqz")) || format == 4) {   // select.t:74
+    // compressed database (char_io.t:18-214): codes of ceil(log2(table size)) bits, most significant bit first;
+    // unpacked here into one code per byte -- the stream the engines see is the .sqn one plus the end-of-sequence
+    // codes that fill up the last buffer
+    normalized_ = true;
+    std::vector<unsigned char> packed, tb;
+    if (!read_file(database + ".sqz", &packed) || !read_file(database + ".tbz", &tb) || tb.empty())
+      die(("Can't open compressed sequence database " + database + ".sqz/.tbz").c_str());
+    table_.assign(tb.begin(), tb.end());
+    unsigned bits = 1;
+    while ((1u << bits) < tb.size()) ++bits;
+    const size_t nchars = packed.size() * 8 / bits;
+    bytes.resize(nchars);
+    size_t bitat = 0;
+    for (size_t i = 0; i < nchars; ++i) {
+      unsigned code = 0;
+      for (unsigned b = 0; b < bits; ++b, ++bitat) code = (code << 1) | ((packed[bitat >> 3] >> (7 - (bitat & 7))) & 1u);
+      bytes[i] = (unsigned char)code;
+    }
   } else if ((format == 0 && file_exists(database + ".seq")) || format == 2) {   // select.t:118
     if (!load(database + ".seq")) die(("Can't open indexed sequence database " + database + ".seq").c_str());
   } else {
-    die("This build reads databases prepared by compress_seq (<db>.seq or <db>.sqn + <db>.tbl, <db>.idb, <db>.hdr);",
-        "run pm_compress_seq -i <fasta> [-n true] first.");
+    die("This build reads databases prepared by compress_seq (<db>.seq, <db>.sqn + <db>.tbl or <db>.sqz + <db>.tbz; <db>.idb, <db>.hdr);",
+        "run pm_compress_seq -i <fasta> [-n true | -z true] first.");
   }
   if (mapped) {
     length_ = (int64_t)map_.size();

@@ -1,7 +1,7 @@
 // seq_io.h -- the data formats either side of the scan path, host C++.
 //
 // * SeqDb: the indexed sequence database written by compress_seq (ours or the reference's):
-//   <db>.seq (characters) or <db>.sqn + <db>.tbl (normalized codes + table), <db>.idb (binary
+//   <db>.seq (characters), <db>.sqn + <db>.tbl (normalized codes + table) or <db>.sqz + <db>.tbz (bit-packed codes), <db>.idb (binary
 //   index) and <db>.hdr (FASTA headers).  Mirrors what primer_match/pcr_match ask of
 //   IndexedFastaFile<...,Lazy_Header_SI> (reference fasta_io.t:142-260,262-435): get_seq_pos,
 //   get_header_data, is_subseq, and the parameter checks of check_fasta_file_params.
@@ -49,7 +49,7 @@ struct HeaderData {                                   // Lazy_Header_SI (fasta_i
 
 class SeqDb {
  public:
-  // format: 0 auto (.sqn, then .seq; select.t:30,118), 2 indexed (.seq), 3 normalized (.sqn+.tbl).
+  // format: 0 auto (.sqn, then .sqz, then .seq; select.t:30,74,118), 2 indexed (.seq), 3 normalized (.sqn+.tbl), 4 compressed (.sqz+.tbz).
   // load_headers = the `alignments && dbindex` argument of pick_fasta_file (primer_match.cc:1093).
   // check = ffp.check_params; upper_case / eos_char: ffp fields (fasta_io.t:18-30).
   // Errors follow the reference: message on stderr, exit(1).

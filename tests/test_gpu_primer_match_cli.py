@@ -80,6 +80,27 @@ def test_kernel_families_and_output_file():
         assert sorted(text.splitlines()[1:]) == sorted(g["cases"]["k1_counts"]["normalized"].splitlines())
 
 
+@pytest.mark.parametrize("fixture", ["cli_a", "cli_b"])
+def test_compressed_database(fixture):
+    """<db>.sqz + <db>.tbz (pm_compress_seq -z true; char_io.t:18-214): the stream is the normalized one plus the
+    end-of-sequence codes that fill the last buffer, so the output is the normalized database's (the real
+    reference prints the same for -D 3 and -D 4).  Picked by itself when there is no .sqn (select.t:74), or -D 4."""
+    g = load(fixture)
+    with tempfile.TemporaryDirectory() as d:
+        prepare(g, d)
+        os.mkdir(os.path.join(d, "compressed"))
+        fa = os.path.join(d, "compressed", "db.fa")
+        with open(fa, "w") as f:
+            f.write(g["fasta"])
+        r = subprocess.run([CS, "-i", fa, "-z", "true"], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert os.path.exists(fa + ".sqz") and not os.path.exists(fa + ".sqn") and not os.path.exists(fa + ".seq")
+        for case in g["cases"]:
+            want = sorted(g["cases"][case]["normalized"].splitlines())
+            for more in ([], ["-D", "4"]):
+                assert sorted(run_case(g, d, case, "compressed", more).splitlines()) == want, (fixture, case, more)
+
+
 def test_refusals():
     g = load("cli_a")
     with tempfile.TemporaryDirectory() as d:
