@@ -7,8 +7,6 @@
 // amplicon-length window on the same strand arrangement, re-aligns both ends, keeps pairs inside
 // one FASTA entry with length in [-m, -M] (and within -d of the UniSTS size) and prints them
 // through the -A format language (pcr_match.cc:339-686).
-//
-// Not built (refused with a message): raw FASTA databases (-D 1).
 #include <unistd.h>
 
 #include <chrono>
@@ -52,7 +50,7 @@ struct Options {
           "  -p <sequences> | -P <file> | -S <unists-file> | -F <fasta-file>   primer pairs (\"-\" = stdin)\n"
           "  -o <output-file>  -k <edits> | -K <mismatches>  -r  -a  -s -e -5 -3 <n|~n>  -u  -w  -W  -E <int>\n"
           "  -m <min amplicon>  -M <max amplicon, default 2000>  -d <deviation from UniSTS size>  -b\n"
-          "  -A <format>  -R <int>  -N <int>  -D (0|2|3|4)  -B  -v  -h\n");
+          "  -A <format>  -R <int>  -N <int>  -D (0|1|2|3|4)  -B  -v  -h\n");
   exit(1);
 }
 
@@ -96,7 +94,6 @@ Options parse(int argc, char **argv) {
   if ((o.primer_arg.empty() || o.db_path.empty()) && !o.chatty) usage();
   if (o.max_edits < 0) usage("Number of mismatches (-k) must be at least 0");
   if (o.db_variant < 0 || o.db_variant > 4) usage("Invalid integer for fasta database indexing (-D).");
-  if (o.db_variant == 1) usage("Raw FASTA databases (-D 1) are not read by this build: indexed (-D 2), normalized (-D 3) or compressed (-D 4); run pm_compress_seq first.");
   return o;
 }
 

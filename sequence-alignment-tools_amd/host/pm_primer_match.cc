@@ -8,7 +8,6 @@
 // editdist_alignment) and printed through the -A / -C mini-languages (primer_match.cc:355-843).
 //
 // Not built (refused with a message): -T (translation), DNA-mutation scoring (-k .N),
-// raw FASTA databases (-D 1; run pm_compress_seq first),
 // the PRIMER3TM escapes %m %G and the peptide-mass escape %M.
 #include <unistd.h>
 
@@ -61,7 +60,7 @@ struct Options {
           "  -u  -w  -W  -E <int>  -c  -a  -M <max>  -A <format>  -C <format>  -R <int>\n"
           "  -N <int>                engine: 0 auto, 16 bit-parallel kernels, 17 seed kernels,\n"
           "                          1..14 = reproduce that reference engine's hit set\n"
-          "  -D (0|2|3|4)  -I  -B  -v  -h\n");
+          "  -D (0|1|2|3|4)  -I  -B  -v  -h\n");
   exit(1);
 }
 
@@ -113,7 +112,6 @@ Options parse(int argc, char **argv) {
   if (o.db_variant < 0 || o.db_variant > 4) usage("Invalid integer for fasta database indexing (-D).");
   if (o.dna_scoring) usage("DNA mutation scoring (-k .N) is not available on the GPU engine.");
   if (o.translated) usage("Translation (-T) is not available on the GPU engine.");
-  if (o.db_variant == 1) usage("Raw FASTA databases (-D 1) are not read by this build: indexed (-D 2), normalized (-D 3) or compressed (-D 4); run pm_compress_seq first.");
   return o;
 }
 

@@ -88,7 +88,7 @@ bool MappedFile::open(const std::string &path) {
 
 SeqDb::SeqDb(const std::string &database, int format, bool load_headers, bool check, bool upper_case, char eos_char, bool memmap) {
   std::vector<unsigned char> bytes;
-  bool mapped = false;
+  bool mapped = false, raw = false;
   auto load = [&](const std::string &path) -> bool {
     if (memmap && map_.open(path)) { mapped = true; return true; }
     return read_file(path, &bytes);
@@ -120,9 +120,52 @@ SeqDb::SeqDb(const std::string &database, int format, bool load_headers, bool ch
     }
   } else if ((format == 0 && file_exists(database + ".seq")) || format == 2) {   // select.t:118
     if (!load(database + ".seq")) die(("Can't open indexed sequence database " + database + ".seq").c_str());
-  } else {
-    die("This build reads databases prepared by compress_seq (<db>.seq, <db>.sqn + <db>.tbl or <db>.sqz + <db>.tbz; <db>.idb, <db>.hdr);",
-        "run pm_compress_seq -i <fasta> [-n true | -z true] first.");
+  } else {                                               // none of the files, or -D 1: the FASTA file itself (select.t:152-186)
+    // StreamedFastaFile (fasta_io.t:448-751) as one pass over the file: newline, carriage return and blank are
+    // skipped, '>' opens a header line, every other character is a stream character; an end-of-sequence character
+    // in front of the first entry (eos_start), between entries and behind the last.  The index (entry start ->
+    // header) comes out of the same pass.  For FASTA files with lines of one length -- the ones the reference
+    // does not warn about -- this is the stream of <db>.seq without compress_seq's character filter.
+    std::vector<unsigned char> in;
+    if (!read_file(database, &in)) die(("Can't open sequence database " + database).c_str());
+    raw = true;
+    bytes.reserve(in.size());
+    bytes.push_back((unsigned char)eos_char);
+    const size_t n = in.size();
+    size_t i = 0;
+    bool ended = false;
+    while (!ended) {
+      if (i >= n) { bytes.push_back((unsigned char)eos_char); break; }
+      unsigned char ch = in[i++];
+      if (ch != '\n' && ch != '\r' && ch != ' ' && ch != '>') {
+        bytes.push_back(upper_case ? (unsigned char)toupper(ch) : ch);
+        continue;
+      }
+      while (ch == '\n' || ch == '\r' || ch == ' ') {
+        if (i >= n) { bytes.push_back((unsigned char)eos_char); ended = true; break; }
+        ch = in[i++];
+      }
+      if (ended) break;
+      if (ch == '>') {
+        const size_t hs = i;
+        while (i < n && in[i] != '\n' && in[i] != '\r') ++i;
+        const size_t he = i;
+        if (i < n) { if (in[i] == '\r' && i + 1 < n && in[i + 1] == '\n') ++i; ++i; }
+        const bool first = bytes.size() == 1;
+        if (!first) bytes.push_back((unsigned char)eos_char);
+        if (load_headers && (keys_.empty() || keys_.back() < (int64_t)bytes.size())) {   // _store_headers (fasta_io.t:468-474)
+          keys_.push_back((int64_t)bytes.size());
+          hdr_off_.push_back((int64_t)hdr_.size());
+          hdr_len_.push_back((int64_t)(he - hs));
+          hdr_.insert(hdr_.end(), in.begin() + hs, in.begin() + he);
+        }
+        if (first && i < n) { const unsigned char c2 = in[i++]; bytes.push_back(upper_case ? (unsigned char)toupper(c2) : c2); }   // (:576-585: taken as it is)
+      } else {
+        bytes.push_back(upper_case ? (unsigned char)toupper(ch) : ch);
+      }
+    }
+    cache_.resize(keys_.size());
+    cached_.assign(keys_.size(), false);
   }
   if (mapped) {
     length_ = (int64_t)map_.size();
@@ -133,7 +176,8 @@ SeqDb::SeqDb(const std::string &database, int format, bool load_headers, bool ch
   }
 
   std::vector<int64_t> ikeys, ivals;
-  const bool need_index = check || load_headers;
+  const bool need_index = (check || load_headers) && !raw;
+  if (raw) check = false;                               // check_fasta_file_params is IndexedFastaFile's (fasta_io.t:267-313)
   if (need_index) {
     std::vector<unsigned char> idb;
     if (!read_file(database + ".idb", &idb) || idb.size() < 8)

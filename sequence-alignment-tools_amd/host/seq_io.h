@@ -49,7 +49,8 @@ struct HeaderData {                                   // Lazy_Header_SI (fasta_i
 
 class SeqDb {
  public:
-  // format: 0 auto (.sqn, then .sqz, then .seq; select.t:30,74,118), 2 indexed (.seq), 3 normalized (.sqn+.tbl), 4 compressed (.sqz+.tbz).
+  // format: 0 auto (.sqn, then .sqz, then .seq, else the FASTA file itself; select.t:30,74,118,152), 1 raw FASTA,
+  // 2 indexed (.seq), 3 normalized (.sqn+.tbl), 4 compressed (.sqz+.tbz).
   // load_headers = the `alignments && dbindex` argument of pick_fasta_file (primer_match.cc:1093).
   // check = ffp.check_params; upper_case / eos_char: ffp fields (fasta_io.t:18-30).
   // Errors follow the reference: message on stderr, exit(1).

@@ -131,16 +131,18 @@ def main():
         out = {"fasta": fasta, "primers_txt": ptxt, "primers_fasta": pfa, "primers_sts": psts, "primers_iupac": wtxt, "cases": {}, "db_files": {}}
         with tempfile.TemporaryDirectory() as d:
             fa = os.path.join(d, "db.fa")
-            for variant, args in [("normalized", ["-n", "true"]), ("indexed", [])]:
+            for variant, args in [("normalized", ["-n", "true"]), ("indexed", []), ("compressed", ["-z", "true"]), ("raw", None)]:
                 sub = os.path.join(d, variant)
                 os.mkdir(sub)
                 fa = os.path.join(sub, "db.fa")
                 with open(fa, "w") as f:
                     f.write(fasta)
+                if args is None:                                    # the FASTA file itself (primer_match -D 1 / no database files)
+                    continue
                 r = run([os.path.join(REF, "compress_seq"), "-i", fa] + args)
                 assert r.returncode == 0, r.stderr
                 files = {}
-                for ext in ("seq", "sqn", "tbl", "hdr", "idb"):
+                for ext in ("seq", "sqn", "tbl", "sqz", "tbz", "hdr", "idb"):
                     if os.path.exists(fa + "." + ext):
                         with open(fa + "." + ext, "rb") as f:
                             files[ext] = base64.b64encode(f.read()).decode()
@@ -149,7 +151,7 @@ def main():
                 with open(os.path.join(d, "primers." + src), "w") as f:
                     f.write(text)
             for cname, src, extra in CASES:
-                for variant in ("normalized", "indexed"):
+                for variant in ("normalized", "indexed", "compressed", "raw"):
                     fa = os.path.join(d, variant, "db.fa")
                     parg = ["-p", " ".join(pats[:5])] if src == "p" else ["-" + ("P" if src == "W" else src), os.path.join(d, "primers." + src)]
                     r = run([os.path.join(REF, "primer_match"), "-i", fa] + parg + extra)

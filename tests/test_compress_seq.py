@@ -27,7 +27,7 @@ def files_of(fa):
 
 
 @pytest.mark.parametrize("fixture", ["cli_a", "cli_b"])
-@pytest.mark.parametrize("variant,args", [("normalized", ["-n", "true"]), ("indexed", [])])
+@pytest.mark.parametrize("variant,args", [("normalized", ["-n", "true"]), ("indexed", []), ("compressed", ["-z", "true"])])
 def test_against_golden_files(fixture, variant, args):
     assert os.path.exists(CS), "run __graft_entry__.build()"
     with open(os.path.join(ROOT, "tests", "golden", fixture + ".json")) as f:

@@ -81,24 +81,62 @@ def test_kernel_families_and_output_file():
 
 
 @pytest.mark.parametrize("fixture", ["cli_a", "cli_b"])
-def test_compressed_database(fixture):
-    """<db>.sqz + <db>.tbz (pm_compress_seq -z true; char_io.t:18-214): the stream is the normalized one plus the
-    end-of-sequence codes that fill the last buffer, so the output is the normalized database's (the real
-    reference prints the same for -D 3 and -D 4).  Picked by itself when there is no .sqn (select.t:74), or -D 4."""
+def test_compressed_and_raw_databases(fixture):
+    """<db>.sqz + <db>.tbz (pm_compress_seq -z true; char_io.t:18-214: the normalized stream plus the end-of-sequence
+    codes that fill the last buffer), picked by itself when there is no .sqn (select.t:74) or with -D 4; and the FASTA
+    file itself (StreamedFastaFile, fasta_io.t:448-751) when there are no database files (select.t:152) or with -D 1.
+    Expected output: the real reference's on the same files (goldens "compressed" / "raw")."""
     g = load(fixture)
     with tempfile.TemporaryDirectory() as d:
         prepare(g, d)
-        os.mkdir(os.path.join(d, "compressed"))
+        for variant in ("compressed", "raw"):
+            os.mkdir(os.path.join(d, variant))
+            fa = os.path.join(d, variant, "db.fa")
+            with open(fa, "w") as f:
+                f.write(g["fasta"])
         fa = os.path.join(d, "compressed", "db.fa")
-        with open(fa, "w") as f:
-            f.write(g["fasta"])
         r = subprocess.run([CS, "-i", fa, "-z", "true"], capture_output=True)
         assert r.returncode == 0, r.stderr
         assert os.path.exists(fa + ".sqz") and not os.path.exists(fa + ".sqn") and not os.path.exists(fa + ".seq")
         for case in g["cases"]:
-            want = sorted(g["cases"][case]["normalized"].splitlines())
-            for more in ([], ["-D", "4"]):
-                assert sorted(run_case(g, d, case, "compressed", more).splitlines()) == want, (fixture, case, more)
+            for variant, flag in (("compressed", "4"), ("raw", "1")):
+                want = sorted(g["cases"][case][variant].splitlines())
+                for more in ([], ["-D", flag]):
+                    assert sorted(run_case(g, d, case, variant, more).splitlines()) == want, (fixture, case, variant, more)
+        # -D 1 reads the FASTA file even when compress_seq's files lie next to it
+        assert sorted(run_case(g, d, "k1_oneline_fwd_only", "normalized", ["-D", "1"]).splitlines()) == sorted(g["cases"]["k1_oneline_fwd_only"]["raw"].splitlines())
+
+
+REF_PM = os.path.join(ROOT, "oracle", "_ref", "primer_match")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PM), reason="reference primer_match not built (oracle/_ref)")
+def test_raw_fasta_layouts_against_the_reference_binary():
+    """The FASTA file itself as database (-D 1) in layouts the reference reads without a warning: CR LF line ends,
+    lower-case bases (matched only with -u), no newline behind the last line, a header with tabs, a one-line entry;
+    same lines as the real primer_match prints."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGT"), size=n).tolist()) for n in (300, 240, 60, 180)]
+    primers = [seqs[0][40:60], seqs[1][100:122], seqs[3][10:30], seqs[2][5:25]]
+    layouts = {
+        "crlf": "".join(">e%d some text\r\n%s" % (i, "".join(s[j:j + 60] + "\r\n" for j in range(0, len(s), 60))) for i, s in enumerate(seqs)),
+        "lower_no_final_newline": "".join(">e%d\ttabbed\n%s" % (i, "".join(s[j:j + 60].lower() + "\n" for j in range(0, len(s), 60))) for i, s in enumerate(seqs))[:-1],
+    }
+    with tempfile.TemporaryDirectory() as d:
+        pf = os.path.join(d, "p.txt")
+        with open(pf, "w") as f:
+            f.write("\n".join(primers) + "\n")
+        for name, text in layouts.items():
+            fa = os.path.join(d, name + ".fa")
+            with open(fa, "wb") as f:
+                f.write(text.encode())
+            for opts in (["-k", "1", "-r"], ["-k", "1", "-r", "-u"], ["-K", "2", "-r", "-u", "-A", "%i %r %s %e %d [%h|%H]\\n"]):
+                want = subprocess.run([REF_PM, "-i", fa, "-P", pf, "-D", "1"] + opts, capture_output=True, timeout=120)
+                got = subprocess.run([PM, "-i", fa, "-P", pf, "-D", "1"] + opts, capture_output=True, timeout=120)
+                assert want.returncode == 0 and got.returncode == 0, (name, opts, got.stderr[-300:])
+                assert sorted(got.stdout.splitlines()) == sorted(want.stdout.splitlines()), (name, opts)
+            assert want.stdout.strip(), name
 
 
 def test_refusals():
@@ -106,6 +144,6 @@ def test_refusals():
     with tempfile.TemporaryDirectory() as d:
         prepare(g, d)
         fa = os.path.join(d, "normalized", "db.fa")
-        for bad in (["-T"], ["-k", ".1"], ["-D", "1"], ["-M", "3"], ["-a"]):
+        for bad in (["-T"], ["-k", ".1"], ["-D", "7"], ["-M", "3"], ["-a"]):
             r = subprocess.run([PM, "-i", fa, "-p", "ACGTACGTACGTACGT"] + bad, capture_output=True)
             assert r.returncode == 1 and r.stdout == b"", bad
