@@ -25,6 +25,13 @@
 //
 // Cost model: ~25 VALU + 1 LDS read per (position, combo), ~0.9*C/10 L2 probes per position.
 // Bound: LDS/VALU issue, then L2 request rate; HBM traffic is 1 byte per base per MALL pass.
+//
+// In this file, in order: the helpers all seed kernels share (packed loads, hashes, the partner test of
+// exact_halves, the exact verify), pm_seed_scan<LW,MODE,HALVES,EDITS> (the plan above: k = 0, windows
+// shorter than 20, and the round-1 forms of the two plans below), pm_edit_scan (first stage of the
+// edit-distance plan: tabulated piece hashes, key map in L2), pm_half_scan (exact_halves -k on a key
+// bitmap + rank directory), the dense second kernels pm_edits_verify / pm_half_verify / pm_bases_verify,
+// pm_pack_stream, and the host side (edit_cover, seed_build, seed_upload, seed_launch).
 #include "pm_internal.h"
 #include "pm_seed.h"
 
