@@ -41,7 +41,7 @@ for name in ("bench_K2", "bench_k0", "bench_K1", "bench_k1_edits", "bench_k2_edi
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, "%s_%s.json" % (tag, name)))
 
-for name in ("stages_k2_edits", "pmc_l2_k2_edits", "sq_k2_edits", "stages_k1_edits"):
+for name in ("stages_k2_edits", "pmc_l2_k2_edits", "sq_k2_edits", "stages_k1_edits", "sq_k1_edits"):
     src = os.path.join(G, "%s_%s.txt" % (tag, name))
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, "%s_%s.txt" % (tag, name)))

@@ -15,6 +15,6 @@ import csv,glob,collections
 for f in sorted(glob.glob("gpurun_out/pmcs_${tag}_*/*/*counter_collection.csv")):
     agg=collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if any(x in r["Kernel_Name"] for x in ("seed_scan", "pair_scan", "edit_scan")): agg[r["Counter_Name"]]+=float(r["Counter_Value"])
+        if any(x in r["Kernel_Name"] for x in ("seed_scan", "pair_scan", "edit_scan", "half_scan")): agg[r["Counter_Name"]]+=float(r["Counter_Value"])
     for k,v in sorted(agg.items()): print("${tag} %-24s %.4g"%(k,v))
 PY
