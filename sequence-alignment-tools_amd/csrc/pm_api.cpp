@@ -490,7 +490,14 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     if (halves_mode && force_lw > 0 && force_lw <= 10) tile_keys = (size_t)1 << 21;
     // halves of >= 10 bases go through the ranked plan (pm_half_scan): its key bitmap has no capacity either, and a
     // tile of 2^20 halves keeps the "further halves of a key" index inside the slot's 20 bits
-    if (halves_mode && force_lw >= 10 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) tile_keys = (size_t)1 << 20;
+    if (halves_mode && force_lw >= 10 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) {
+      size_t fits = 0;                                 // seed_build's rule: the ranked plan when >= 90 % of the halves fit its partner test
+      for (size_t i = 0; i < sp.size(); ++i) {
+        const int L = (int)sp[i].s.size(), plen = (int)partners[i].size();
+        if (sides[i] ? L + plen + h->cfg.k <= 32 : plen + h->cfg.k <= 16) ++fits;
+      }
+      if (fits * 10 >= sp.size() * 9) tile_keys = (size_t)1 << 20;
+    }
     if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
     const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
     size_t per = (sp.size() + ntile - 1) / ntile;

@@ -2033,8 +2033,17 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       memcpy(rec + 24, &idv, 4);
     }
   }
-  // exact_halves -k, ranked form: halves of >= 10 bases, key = their last ten
-  if (partners && np > 0 && lmin >= 10 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) {
+  // exact_halves -k, ranked form: halves of >= 10 bases, key = their last ten.  Its partner test needs the partner's
+  // window inside the 48 stream bases a queue entry carries (half_partner_fast); a half whose window does not fit
+  // (patterns of 31, 32 characters) passes unfiltered, which is fine for a few of them -- a set made of such
+  // patterns stays on the round-1 form, whose filter reads the stream itself.
+  size_t half_fits = 0;
+  if (partners)
+    for (size_t j = 0; j < np; ++j) {
+      const int L = (int)pats[j].s.size(), plen = t.part_len[j];
+      if (t.part_side[j] ? L + plen + halves_k <= 32 : plen + halves_k <= 16) ++half_fits;
+    }
+  if (partners && np > 0 && lmin >= 10 && half_fits * 10 >= np * 9 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) {
     std::vector<uint64_t> srt(np);
     for (size_t j = 0; j < np; ++j) {
       const std::string &s = pats[j].s;

@@ -590,6 +590,17 @@ def test_exact_halves_edits_plans(env, monkeypatch):
             pm.close()
             assert len(want) > 100
             assert got == want, (env, tbl is None, k, len(got), len(want))
+    # a set of 32-mers only: no half fits the ranked plan's partner test, the round-1 form takes the set
+    long_pats = [p for p in synth.make_patterns(rng, ents, 60, length=32, planted=0.9, indel_frac=0.5, extras=False) if len(p) in (31, 32) and set(p) <= set("ACGT")]
+    text = O.Text(codes, table)
+    want = O.sorted_tuples(O.find_all(text, long_pats, engine=sat_amd.SEM_EXACT_HALVES, k=1, indels=True))
+    pm = sat_amd.PatternMatch(k=1, indels=True, semantics=sat_amd.SEM_EXACT_HALVES, kernel=sat_amd.KERNEL_SEED)
+    for i, p in enumerate(long_pats):
+        pm.add_pattern(p, i + 1)
+    pm.init(codes, table)
+    assert "pm_half_scan" not in pm.describe()
+    assert sat_amd.sorted_tuples(pm.find_all()) == want and len(want) > 10
+    pm.close()
 
 
 def test_edit_distance_device_text_with_repeat_clusters():
