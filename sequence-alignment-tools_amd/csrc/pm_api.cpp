@@ -67,6 +67,7 @@ struct pm_handle {
   bool bases_edits = false;           // exact_bases -k on the seed family: the k-error automaton's candidates -> block seeds (pm_bases_seeds)
   int64_t own_begin = 0, own_end = 0; //   the range the caller asked for (the candidates are scanned a little wider)
   bool halves_dev = false;            // exact_halves -k: half seeds extended by pm_seed_extend on the GPU
+  bool half_ranked_any = false;       // ... and some pattern tile runs on pm_half_scan (needs the seed record buffer)
   bool edits_dev = false;             // filter_bitvec / shift_and_inexact -k on the seed kernels: records deduplicated after the scan
   unsigned long long *d_seed_count = nullptr;   // edits: [0] unused, [1+t] seed records of tile t
   uint64_t *d_seeds = nullptr;                  // edits: 8-byte seed records between the scan and the verify kernel
@@ -413,7 +414,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   { void *lazy[] = {h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_fpat_len, h->d_fpat_id}; for (void *q : lazy) if (q) (void)hipFree(q); }
   h->d_dp_codes = nullptr; h->d_dp_esb = h->d_dp_eeb = nullptr; h->d_fpat_len = nullptr; h->d_fpat_id = nullptr;
   h->d_final = nullptr; h->n_final = 0;
-  h->seed_flags = false; h->bases_flags = false; h->bases_edits = false;
+  h->seed_flags = false; h->bases_flags = false; h->bases_edits = false; h->half_ranked_any = false;
   h->zoned = false;
   for (const Pattern &p : h->pats) h->zoned = h->zoned || p.esb || p.eeb;
   h->start_cached = false; h->start_cache.clear();
@@ -565,6 +566,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       h->bases_flags = h->sem == PM_SEM_EXACT_BASES && !h->cfg.indels;
       h->bases_edits = h->sem == PM_SEM_EXACT_BASES && h->cfg.indels;
       h->halves_dev = halves_mode;
+      h->half_ranked_any = h->sd.half_ranked;
+      for (const SeedDevice &d : h->sd_more) h->half_ranked_any = h->half_ranked_any || d.half_ranked;
       h->edits_dev = edits_mode;
       if (halves_mode) {
         const size_t nh = h->inner.size();
@@ -591,7 +594,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     }
   }
   if (!want_seed) {
-    h->halves_dev = false; h->edits_dev = false;
+    h->halves_dev = false; h->edits_dev = false; h->half_ranked_any = false;
     std::fill(h->in_rest.begin(), h->in_rest.end(), 0); h->nrest = 0;
     h->kern = PM_KERNEL_BITPAR;
     BitparTables tabs;
@@ -803,7 +806,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
     begin = begin > reach ? begin - reach : 0;
     end = std::min<int64_t>(h->n, end + reach);
   }
-  if (h->kern == PM_KERNEL_SEED && (h->edits_dev || (h->halves_dev && h->sd.half_ranked)))
+  if (h->kern == PM_KERNEL_SEED && (h->edits_dev || (h->halves_dev && h->half_ranked_any)))
   {
     // per pattern tile: scan kernel -> seed records in d_ext, verify kernel -> candidates in d_cands
     // ~1 seed record per 8 bases at 200k patterns (key matches that pass the four-base-word test)
@@ -1024,6 +1027,19 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   if (n_out) *n_out = cnt;
   if (cnt > h->cap) { h->last_count = 0; return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
   h->last_count = cnt;
+  if (h->edits_dev || (h->halves_dev && h->half_ranked_any)) {
+    // the seed buffer of a tile must have held all its seed records
+    unsigned long long worst = 0;
+    for (int t = 0; t < 1 + (int)h->sd_more.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] %s: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", h->edits_dev ? "edits" : "halves", worst, h->seed_cap, cnt);
+    if (worst > h->seed_cap) {                                     // grow the seed buffer and tell the caller to scan again
+      (void)hipFree(h->d_seeds); h->d_seeds = nullptr;
+      h->seed_cap = (size_t)worst + (size_t)worst / 8 + 1024;
+      h->last_count = 0;
+      if (n_out) *n_out = h->cap + 1;                                // "> cap": pm_scan's retry condition
+      return fail(h, PM_E_OVERFLOW, "seed buffer was too small; it has been enlarged, scan the range again");
+    }
+  }
   if (h->halves_dev) {
     // second device pass: banded DP next to every surviving seed (pm_extend.hip); the records
     // handed on are the successful extensions
@@ -1048,19 +1064,6 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
       h->last_count = 0;
       if (n_out) *n_out = std::max<size_t>(cnt, h->cap) + 1;         // "> cap": the callers' grow-and-rescan condition
       return fail(h, PM_E_OVERFLOW, "suspect buffer was too small; it has been enlarged, scan the range again");
-    }
-  }
-  if (h->edits_dev || (h->halves_dev && h->sd.half_ranked)) {
-    // the seed buffer of a tile must have held all its seed records
-    unsigned long long worst = 0;
-    for (int t = 0; t < 1 + (int)h->sd_more.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] %s: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", h->edits_dev ? "edits" : "halves", worst, h->seed_cap, cnt);
-    if (worst > h->seed_cap) {                                     // grow the seed buffer and tell the caller to scan again
-      (void)hipFree(h->d_seeds); h->d_seeds = nullptr;
-      h->seed_cap = (size_t)worst + (size_t)worst / 8 + 1024;
-      h->last_count = 0;
-      if (n_out) *n_out = h->cap + 1;                                // "> cap": pm_scan's retry condition
-      return fail(h, PM_E_OVERFLOW, "seed buffer was too small; it has been enlarged, scan the range again");
     }
   }
   if (h->edits_dev) {

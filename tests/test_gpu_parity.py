@@ -601,6 +601,17 @@ def test_exact_halves_edits_plans(env, monkeypatch):
     assert "pm_half_scan" not in pm.describe()
     assert sat_amd.sorted_tuples(pm.find_all()) == want and len(want) > 10
     pm.close()
+    # pattern tiles of both kinds in one handle: the first tile is made of the 32-mers (round-1 form), the second of 22-mers (ranked)
+    monkeypatch.setenv("PM_SEED_TILE", str(2 * len(long_pats)))
+    mixed = long_pats + [p for p in pats if len(p) == 22][:len(long_pats)]
+    want = O.sorted_tuples(O.find_all(text, mixed, engine=sat_amd.SEM_EXACT_HALVES, k=1, indels=True))
+    pm = sat_amd.PatternMatch(k=1, indels=True, semantics=sat_amd.SEM_EXACT_HALVES, kernel=sat_amd.KERNEL_SEED)
+    for i, p in enumerate(mixed):
+        pm.add_pattern(p, i + 1)
+    pm.init(codes, table)
+    assert "tiles=2" in pm.describe(), pm.describe()
+    assert sat_amd.sorted_tuples(pm.find_all()) == want
+    pm.close()
 
 
 def test_edit_distance_device_text_with_repeat_clusters():
