@@ -2266,6 +2266,7 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   a.packed = d_packed; a.npacked = (n + 15) / 16;
   a.chunk_len = g.seg_len; a.chunk0 = (d.edits && begin > d.edits ? begin - d.edits : (d.edits ? 0 : begin)) / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;                                                   // one run ~ one chunk per CU
+  if (d.edits && d.edit_tabulated) a.group = 512;                   // pm_edit_scan (3 Gbp, 100k primers): 128: 86.8 ms, 256: 82.2, 512: 81.3, 1024: 81.1, 2048: 83.9
   if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
   a.debug = 0;
