@@ -988,16 +988,17 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 //   * The key hash is tabulated per piece: H = F0(first piece) ^ F1(second) ^ F2(third), F = 24-bit
 //     multiply + fold of one byte (edit_piece_hash).  A lane computes the F values of the bytes its
 //     eight windows can use once per half block (two SDWA instructions per value: the byte select rides
-//     on the multiply) and every test is then one three-way XOR (v_bitop3) of registers picked at compile time --
-//     no funnel shifts, no piece merging, no multiply per test.
+//     on the multiply) and every test is then one three-way XOR (v_bitop3) of registers picked at
+//     compile time -- no funnel shifts, no piece merging, no multiply per test.
 //   * The combo's filter in LDS is a blocked Bloom filter addressed by H itself: dword at byte
-//     H & 0x1fffc, bits (H >> 16) & 31, (H >> 24) & 31, (H >> 19) & 31 (three SDWA shifts).
-//   * Survivors (12 % at 200k patterns) look their key up in a 2^24-bit map in L2 (2 MiB per combo:
-//     dword H >> 13, bit (H >> 8) & 31 -- 24 hash bits, so 1.2 % of the false survivors get through at
-//     200k keys): a branch-free dword load per test -- non-survivors read dword 0, one cached line --
-//     consumed one unit later with one SDWA shift.  That replaces the compaction of every Bloom survivor into an LDS
-//     queue and the second-level bitmap: only the ~1.3 % of the tests that are real 12-base key matches
-//     are compacted (ballot + mbcnt), probed in the bucket table and put to the q-gram test.
+//     H & 0x1fffc, bits (H >> 16) & 31, (H >> 24) & 31 and five bits of H >> et_shift (three SDWA
+//     shifts; et_shift = 12 for the default map size).
+//   * Survivors (12 % at 200k patterns) look their key up in a 2^23-bit map in L2 (1 MiB per combo:
+//     dword H >> 14, bit (H >> 8) & 31 -- 2.4 % of the false survivors get through at 200k keys): a
+//     branch-free dword load per test -- non-survivors read dword 0, one cached line -- consumed one
+//     unit later with one SDWA shift.  That replaces the compaction of every Bloom survivor into an
+//     LDS queue and the second-level bitmap: only the ~1.3 % of the tests that are real 12-base key
+//     matches are compacted (ballot + mbcnt), probed in the bucket table and put to the word counts.
 // One instance per combo (pieces and displacement list are template parameters: all register indices
 // and stream offsets are immediates); the lists are edit_cover's, checked on the host at upload.
 constexpr uint32_t EDIT_MUL0 = 0x9E3779u, EDIT_MUL1 = 0xC2B2AFu, EDIT_MUL2 = 0x85EBCBu;
@@ -1990,7 +1991,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.bloom.assign((size_t)C * SEED_BLOOM_STRIDE, 0);
   int lb2 = 16;
   while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2;
-  if (edits) lb2 = 5;                              // pm_edit_scan has its byte table instead (the older first stage builds the bitmap on request)
+  if (edits) lb2 = 5;                              // pm_edit_scan has its key map instead (the older first stage builds the bitmap on request)
   if (edit_bloom_v1) { lb2 = 16; while (((size_t)1 << lb2) < 20 * np && lb2 < 26) ++lb2; }
   t.lb2 = lb2;
   t.bitmap2.assign((size_t)C << (lb2 - 5), 0);
@@ -2104,7 +2105,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       const uint32_t hsel = bloom_selectors(ss);
       static_assert(SEED_BLOOM_WORDS == 1 << 15, "block address = h >> 15");
       if (!t.etable.empty()) {
-        // pm_edit_scan: tabulated key hash, filter block addressed by the hash itself, byte table by its top 21 bits
+        // pm_edit_scan: tabulated key hash, filter block addressed by the hash itself, key map by its top bits
         const uint64_t W = ((uint64_t)whi << 32) | wlo;
         const uint32_t H = edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][0])) & 0xffu, EDIT_MUL0) ^
                            edit_piece_hash((uint32_t)(W >> (8 * t.combos[ci][1])) & 0xffu, EDIT_MUL1) ^
