@@ -142,8 +142,13 @@ __global__ void pm_dedup_unpack(const uint64_t *keys, size_t n, pm_hit *out, uns
 constexpr int DP_MAXL = 32, DP_MAXDELTA = 10, DP_MAXW = DP_MAXDELTA + 2 * 3 + 2;
 enum : uint8_t { D_EQ = 2, D_SUB = 8, D_INS = 16, D_DEL = 32, D_VIOL = 64, D_END = 128 };
 
+// The stream window (<= DP_MAXL + 3 + DP_MAXDELTA + 1 characters) and the pattern are copied into LDS first (byte i of
+// thread t at i * DP_THREADS + t): read cell by cell from global memory, a dependent byte load per cell, they were
+// most of the kernel's time.
+constexpr int DP_THREADS = 256, DP_WIN = 48;
 __device__ bool device_editdist(const uint8_t *text, int64_t n, int64_t end, int64_t end2, const uint8_t *pat, int L,
-                                int lconst, int rconst, int k, bool indels, int eos, int64_t *out_end, int *out_value) {
+                                int lconst, int rconst, int k, bool indels, int eos, int64_t *out_end, int *out_value,
+                                uint8_t *swin, uint8_t *spat) {
   uint8_t dp[(DP_MAXL + 1) * DP_MAXW], fl[(DP_MAXL + 1) * DP_MAXW];
   const int viol = 5 * k + 1, b = indels ? k : 0;
   int64_t ws = 0;
@@ -151,7 +156,10 @@ __device__ bool device_editdist(const uint8_t *text, int64_t n, int64_t end, int
   const int buflen = (int)(end2 - ws), delta = (int)(end2 - end);
   const int W = delta + 2 * b + 2;
   auto at = [&](int p, int t) { return p * W + (t - (p - b)); };
-  auto tch = [&](int t) -> int { const int64_t q = ws + (buflen - t); return q >= 0 && q < n ? (int)text[q] : 0; };   // win[buflen - t]
+  for (int i = 0; i <= buflen && i < DP_WIN; ++i) { const int64_t q = ws + i; swin[i * DP_THREADS] = q >= 0 && q < n ? text[q] : (uint8_t)0; }
+  for (int i = 0; i < L; ++i) spat[i * DP_THREADS] = pat[i];
+  pat = nullptr;
+  auto tch = [&](int t) -> int { return (int)swin[(buflen - t) * DP_THREADS]; };   // win[buflen - t]
   int lbexact = 0, rbexact = L + 1;                                // :230-233
   if (lconst > 0) rbexact = L + 1 - lconst;
   if (rconst > 0) lbexact = rconst;
@@ -169,7 +177,7 @@ __device__ bool device_editdist(const uint8_t *text, int64_t n, int64_t end, int
   }
   for (int p = 1; p <= L; ++p) {                                   // :296-437
     const int lb = p - b > 1 ? p - b : 1, ub = buflen < p + delta + b ? buflen : p + delta + b;
-    const int pc = pat[L - p];
+    const int pc = spat[(L - p) * DP_THREADS];
     const bool zone_sub = (p <= lbexact || p >= rbexact), zone_ins = (p < lbexact || p >= rbexact);
     int rowmin = viol;
     for (int t = lb; t <= ub; ++t) {
@@ -229,6 +237,7 @@ __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels,
                               const uint8_t *pat_codes, const uint8_t *pat_len, const int32_t *esb, const int32_t *eeb,
                               const uint32_t *pat_id, OwnedRange own, pm_hit *out, unsigned long long *out_count,
                               pm_hit *left, unsigned long long *left_count) {
+  __shared__ uint8_t swin[DP_WIN * DP_THREADS], spat[DP_MAXL * DP_THREADS];   // device_editdist's copies of window and pattern
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t key = keys[i];
@@ -263,7 +272,7 @@ __global__ void pm_cluster_dp(const uint64_t *keys, size_t n, int k, int indels,
     return;
   }
   int64_t rend = 0; int rval = 0;
-  if (device_editdist(text, ntext, end, prev, pat_codes + (size_t)(pid - 1) * 32, L, esb[pid - 1], eeb[pid - 1], k, indels != 0, eos, &rend, &rval) &&
+  if (device_editdist(text, ntext, end, prev, pat_codes + (size_t)(pid - 1) * 32, L, esb[pid - 1], eeb[pid - 1], k, indels != 0, eos, &rend, &rval, swin + threadIdx.x, spat + threadIdx.x) &&
       hit_owned(own, rend)) {
     const unsigned long long o = wave_reserve_slot(out_count);
     pm_hit h;
