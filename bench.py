@@ -11,8 +11,8 @@ cluster/verify on rank 0 -> final hits resident on the host of rank 0.
 
 The database is sharded by stream position across ranks: rank r holds and scans
 stream range [r*S, (r+1)*S) plus a 256-byte halo on either side; every rank holds all patterns.
-Default scaling is weak (S = --db-bases per GPU, the 3 Gbp configuration per GPU);
---scaling strong splits a fixed --db-bases database over the ranks.
+Default scaling is strong: the --db-bases database (3 Gbp, BASELINE.json's "3 Gbp DB at 1/2/4/8 GPUs")
+is split over the ranks; --scaling weak scans --db-bases per GPU instead.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -213,13 +213,46 @@ def measured_traffic(args, shard):
     (profiles/traffic_r*.json, produced by scripts/profile_round.sh), or None when this exact
     workload was not profiled."""
     import glob
-    best = None
+    best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
         with open(f) as fh:
             for e in json.load(fh).get("entries", []):
                 if (e["k"], e["indels"], e["db_bases"], e["primers"]) == (args.k, args.indels, shard, args.primers):
-                    best = e["traffic_bytes"]
+                    best = (e["traffic_bytes"], "profiles/" + os.path.basename(f))
     return best
+
+
+def issue_roofline(args, shard, kms):
+    """SURVEY 8(d) "honest secondary bound" for the seed family: the kernels are not HBM bound; which on-chip
+    pipe is how busy, from the committed PMC passes of this exact workload (profiles/issue_r*.json, made by
+    scripts/pmc_issue.sh) and THIS run's kernel time:
+      valu  = VALU wave-instructions / (256 CUs x 4 SIMDs x kernel cycles / 2): a wave64 VALU instruction holds its SIMD-32 for 2 cycles
+      lds   = LDS-array active cycles (incl. bank conflicts), summed over the CUs / (256 x kernel cycles)
+      l1_l2 = L1 -> L2 read requests (one 128-byte line each) / (256 CUs x 0.5 lines per cycle: the 64 B/clk L2 -> L1 return path)
+    at the 2.4 GHz peak clock (the chip clocks lower under load, so the fractions are lower bounds)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "issue_r*.json"))):
+        with open(f) as fh:
+            for e in json.load(fh).get("entries", []):
+                if (e["k"], e["indels"], e["db_bases"], e["primers"]) == (args.k, args.indels, shard, args.primers):
+                    best = (e, "profiles/" + os.path.basename(f))
+    if best is None or not (kms > 0):
+        return None
+    e, src = best
+    cyc = kms * 1e-3 * 2.4e9
+    out = {"source": src, "kernel": e.get("kernel"), "clock_ghz": 2.4, "kernel_ms": kms}
+    if e.get("SQ_INSTS_VALU"):
+        out["valu"] = {"wave_instructions": e["SQ_INSTS_VALU"], "frac": e["SQ_INSTS_VALU"] / (256 * 4 * cyc / 2)}
+    if e.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds"] = {"active_cycles": e["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": e.get("SQ_LDS_BANK_CONFLICT"),
+                      "frac": e["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)}
+    if e.get("TCP_TCC_READ_REQ_sum"):
+        out["l1_l2"] = {"read_requests": e["TCP_TCC_READ_REQ_sum"], "frac": e["TCP_TCC_READ_REQ_sum"] / (256 * 0.5 * cyc)}
+    fr = {k: v["frac"] for k, v in out.items() if isinstance(v, dict)}
+    if fr:
+        out["binding"] = max(fr, key=fr.get)
+    return out
 
 
 def main():
@@ -227,7 +260,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--db-bases", type=int, default=3_000_000_000, help="stream bytes per GPU (weak) or total (strong)")
+    ap.add_argument("--db-bases", type=int, default=3_000_000_000, help="stream bytes in total (strong, the default) or per GPU (weak)")
     ap.add_argument("--entries", type=int, default=24)
     ap.add_argument("--primers", type=int, default=100_000)
     ap.add_argument("--length", type=int, default=20)
@@ -235,7 +268,7 @@ def main():
     ap.add_argument("--indels", type=int, default=0, help="0: -K (mismatches), 1: -k (edits)")
     ap.add_argument("--kernel", choices=["auto", "bitpar", "seed"], default="auto")
     ap.add_argument("--odd", type=int, default=0, help="replace this many primers by ones with an N in the middle (they go to the bit-parallel residue engine)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--cpu-sample", type=int, default=0, help="bases for the CPU baseline (0 = auto, -1 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the one-reference-process-per-core figure")
@@ -255,8 +288,12 @@ def main():
     local = local % ndev if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # PM_BENCH_FORCE_DIST=1: take the N > 1 code (process group, count exchange, owned finalize, gather,
+    # side-stream landing) with a world of one -- the only way to execute the RCCL path on a 1-GPU box
+    force_dist = world == 1 and os.environ.get("PM_BENCH_FORCE_DIST", "") == "1"
+    use_dist = world > 1 or force_dist
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -283,7 +320,7 @@ def main():
         primers, planted = make_primers(stream[:min(stream.numel(), 1 << 26, max(total // 8, 1 << 16))], args.primers, args.length, 7)
     else:
         primers = None
-    if world > 1:
+    if use_dist:
         box = [primers]
         dist.broadcast_object_list(box, src=0, device=cdev)
         primers = box[0]
@@ -302,11 +339,13 @@ def main():
     begin, end = lo - glo, hi - glo
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     kernel_ms = []
+    exch_host_ms = []                                               # per step: host wall time inside the exchange calls (counts + gather)
+    exch_events = []                                                # nccl: (start, end) events on the current stream around the record gather
     final_hits = [0]
     cand_count = [0]
     rescans = [0]
@@ -316,7 +355,7 @@ def main():
     out_pin = torch.empty((1 << 24) * 16, dtype=torch.uint8, pin_memory=True)
     out_buf = out_pin.numpy().view(sat_amd.HIT_DTYPE)
     # filter_bitvec: every rank clusters and verifies what it owns; only final hits travel
-    own_path = world > 1 and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC
+    own_path = use_dist and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC
     g_lo = 0 if glo == 0 else begin - GUARD
     g_hi = stream.numel() if ghi == total else end + GUARD
     land_stream = torch.cuda.Stream(device=dev) if rank == 0 and own_path else None
@@ -366,6 +405,23 @@ def main():
                 pad[:cnt * 2] = torch.from_numpy(pm.copy_records(ptr, cnt).view(np.int64).reshape(-1))
         return pad
 
+    def timed_gather(ptr, cnt, cl, tx0):
+        """padded gather of every rank's records to rank 0 (a record = two int64 words); books the
+        exchange's host time (from tx0, the start of the count exchange) and, on the nccl backend,
+        brackets the transfer with events on the current stream"""
+        ev = None
+        if cdev.type == "cuda":
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        pad = records_for_gather(ptr, cnt, max(max(cl), 1))
+        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, gathered, dst=0)
+        if ev:
+            ev[1].record()
+            exch_events.append(ev)
+        exch_host_ms.append((time.perf_counter() - tx0) * 1e3)
+        return gathered
+
     def finalize_rank0(ptr, cnt, scanned_to):
         """records in HBM -> final hits on the host of rank 0"""
         if dev_final[0]:
@@ -375,7 +431,7 @@ def main():
                 if e.code != -2:
                     raise
                 dev_final[0] = False
-        if world > 1 and pm.selected()[1] == sat_amd.KERNEL_BITPAR and pm.selected()[0] in (sat_amd.SEM_EXACT_HALVES, sat_amd.SEM_EXACT_BASES, sat_amd.SEM_FILTER_BITVEC) and args.indels:
+        if use_dist and pm.selected()[1] == sat_amd.KERNEL_BITPAR and pm.selected()[0] in (sat_amd.SEM_EXACT_HALVES, sat_amd.SEM_EXACT_BASES, sat_amd.SEM_FILTER_BITVEC) and args.indels:
             raise SystemExit("bench.py --gpus>1: this option set verifies on the host with stream text, which rank 0 does not hold (DESIGN.md 5)")
         cands = pm.copy_records(ptr, cnt)
         pm.reset()
@@ -389,12 +445,11 @@ def main():
                 # sort, clustering (and for -k the cluster DPs) on this rank's GPU; the final hits stay in HBM
                 ptr, cnt = pm.finalize_device(0, sort=False, owned=(begin, end, g_lo, None if ghi == total else g_hi), keep=True)
             # the path's one exchange: final hit records to rank 0 over xGMI
+            tx0 = time.perf_counter()
             cl = exchange_counts(cnt, need)
             if cl is not None:
                 break
-        pad = records_for_gather(ptr, cnt, max(max(cl), 1))
-        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, gathered, dst=0)
+        gathered = timed_gather(ptr, cnt, cl, tx0)
         if rank == 0:
             # landing on the host: index fix-up and copy into pinned memory on a side stream, so that it
             # overlaps the next step's scan (the timed region ends with a device-wide synchronize)
@@ -420,7 +475,7 @@ def main():
     def step():
         if own_path:
             return step_owned()
-        if world == 1:
+        if not use_dist:
             while True:
                 ncand, need = scan(begin, end)
                 if not need:
@@ -435,12 +490,11 @@ def main():
             ncand, need = scan(begin, end)
             ptr, cnt = (0, 0) if need else pm.candidates_device()
             # the path's one real exchange: variable-length hit records to rank 0 over xGMI
+            tx0 = time.perf_counter()
             cl = exchange_counts(cnt, need)
             if cl is not None:
                 break
-        pad = records_for_gather(ptr, cnt, max(max(cl), 1))   # a record = two int64 words
-        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, gathered, dst=0)
+        gathered = timed_gather(ptr, cnt, cl, tx0)
         if rank == 0:
             parts = []
             for r in range(world):
@@ -464,7 +518,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -497,7 +551,19 @@ def main():
             planted = want
             if found_planted != len(planted):
                 raise SystemExit("bench.py: only %d of %d planted primer sites were reported" % (found_planted, len(planted)))
+    # per-rank scan kernel time and the exchange's device time (outside the timed region)
+    kms_mine = float(np.mean(kernel_ms[args.warmup:])) if len(kernel_ms) > args.warmup else float("nan")
+    kms_all, exch_dev_ms = [kms_mine], None
+    if use_dist:
+        torch.cuda.synchronize()
+        box = [None] * world
+        dist.all_gather_object(box, kms_mine)
+        kms_all = [float(x) for x in box]
+        evs = exch_events[args.warmup:]
+        if evs:
+            exch_dev_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     if rank == 0:
+        traffic, traffic_source = measured_traffic(args, shard)
         ms_per_step = dt / args.steps * 1e3
         value = n_bases_total / (dt / args.steps) / 1e9
         kms = float(np.mean(kernel_ms[args.warmup:])) if len(kernel_ms) > args.warmup else float("nan")
@@ -509,11 +575,14 @@ def main():
             "metric": baseline_metric(),
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "ranks_seen": dist.get_world_size() if world > 1 else 1, "pack_ms": pm.pack_time(),
+            "ranks_seen": dist.get_world_size() if use_dist else 1, "pack_ms": pm.pack_time(),
+            # the one-off 2-bit re-encoding of the stream (untimed, at init) charged to a single cold pass
+            "value_including_pack": n_bases_total / (dt / args.steps + pm.pack_time() * 1e-3) / 1e9,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%d x %d-mer primers, both strands (%d patterns), %s %d, %s Gbp stream per GPU x %d GPU(s), %d entries"
+            "config": {"workload": "%d x %d-mer primers, both strands (%d patterns), %s %d, %s Gbp stream in total = %s Gbp per GPU x %d GPU(s), %d entries"
                                    % (args.primers, args.length, len(allp), "-k" if args.indels else "-K", args.k,
-                                      ("%.3g" % (shard / 1e9)), world, args.entries),
+                                      ("%.3g" % (total / 1e9)), ("%.3g" % (shard / 1e9)), world, args.entries * (world if args.scaling == "weak" else 1)),
+                       "db_bases_total": total, "db_bases_per_gpu": shard,
                        "semantics": pm.selected()[0], "kernel_family": pm.selected()[1], "kernel": desc,
                        "final_hits": final_hits[0], "candidates": cand_count[0],
                        "planted_found": None if found_planted is None else "%d of %d" % (found_planted, len(planted)),
@@ -521,9 +590,19 @@ def main():
                        "stream": "1 B/base resident in HBM before the timed region; the handle's init (untimed, with the pattern tables) "
                                  "also derives its 2-bit form, which the seed kernels' first stage reads"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, shard),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kms, "algorithmic_bytes": alg_bytes},
         }
+        if use_dist:
+            res["config"]["exchange"] = {"backend": backend, "forced_at_world_1": bool(force_dist),
+                                         "form": "owned finalize on every rank, final hits gathered" if own_path else "candidate records gathered, rank 0 finalizes"}
+            res["exchange_ms"] = float(np.mean(exch_host_ms[args.warmup:])) if len(exch_host_ms) > args.warmup else None
+            res["exchange_device_ms"] = exch_dev_ms
+            res["kernel_ms_per_rank"] = kms_all
+        if pm.selected()[1] == sat_amd.KERNEL_SEED:
+            ir = issue_roofline(args, shard, kms)
+            if ir:
+                res["issue_roofline"] = ir
         # the streaming-read rate this box sustains (same 16-byte loads, nothing else to do)
         try:
             mb = min(stream.numel(), 1 << 31) // 16 * 16
@@ -552,7 +631,7 @@ def main():
                 res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     pm.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

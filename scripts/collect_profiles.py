@@ -79,4 +79,16 @@ if entries:
             "for wide coalesced streams). Fabric-side count: Infinity Cache hits are included.")
     with open(os.path.join(P, "traffic_%s.json" % tag), "w") as f:
         json.dump({"note": note, "entries": entries}, f, indent=1)
+issue = []
+for f in sorted(glob.glob(os.path.join(G, "%s_issue_*.json" % tag))):       # scripts/pmc_issue.sh: one option set each
+    with open(f) as fh:
+        e = json.load(fh)
+    if e.get("SQ_INSTS_VALU") or e.get("TCP_TCC_READ_REQ_sum"):
+        issue.append(e)
+if issue:
+    note = ("rocprofv3 --pmc, one launch of the scan kernel at 3 Gbp x 100k primers (scripts/pmc_issue.sh): SQ counters are sums over the chip "
+            "(SQ_INSTS_* = wave-level instructions, SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT = LDS-array cycles summed over the CUs, "
+            "SQ_WAVE_CYCLES / SQ_WAIT_* = quad-cycles summed over the waves); TCP_TCC_READ_REQ_sum = L1 -> L2 read requests, one 128-byte line each.")
+    with open(os.path.join(P, "issue_%s.json" % tag), "w") as f:
+        json.dump({"note": note, "entries": issue}, f, indent=1)
 print({"%s/%s" % k: v for k, v in counters.items()})

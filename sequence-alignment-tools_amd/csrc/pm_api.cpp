@@ -39,6 +39,7 @@ void Alphabet::set_table(const uint8_t *table, int len) {      // char_io.t:222-
 
 struct pm_handle {
   pm_config cfg{};
+  Knobs knobs;                        // the environment's test / measurement knobs as pm_create found them
   std::vector<Pattern> pats;
   std::unordered_map<uint32_t, uint32_t> id2idx;   // caller's pattern id -> index into pats
   Alphabet alpha;
@@ -173,6 +174,22 @@ extern "C" int pm_pick_semantics(int32_t alphabet_size, int32_t acgt_normalized,
   return PM_SEM_FILTER_BITVEC;                                     // :137-139
 }
 
+// The one place the library looks at its environment (see Knobs, pm_internal.h).
+static void read_knobs(Knobs *k) {
+  auto num = [](const char *name) -> long long { const char *v = getenv(name); return v && *v ? atoll(v) : 0; };
+  auto is = [](const char *name, const char *val) { const char *v = getenv(name); return v && !strcmp(v, val); };
+  *k = Knobs();
+  k->seed_chunk = num("PM_SEED_CHUNK"); k->seed_group = (int)num("PM_SEED_GROUP"); k->seed_debug = (int)num("PM_SEED_DEBUG");
+  k->seed_tile = (long)num("PM_SEED_TILE");
+  if (const char *v = getenv("PM_PAIR")) k->pair = atoi(v);
+  k->pair_row = (int)num("PM_PAIR_ROW");
+  k->half_bloom = is("PM_HALF_SCAN", "bloom"); k->edit_bloom = is("PM_EDIT_SCAN", "bloom");
+  k->edit_table_log = (int)num("PM_EDIT_TABLE_LOG");
+  if (const char *v = getenv("PM_BITPAR_TP")) k->bitpar_tp = atoi(v) != 0;
+  k->bitpar_seglen = num("PM_BITPAR_SEGLEN");
+  k->debug = getenv("PM_DEBUG") != nullptr;
+}
+
 extern "C" int pm_create(const pm_config *cfg, pm_handle **out) {
   if (!cfg || !out) return fail(nullptr, PM_E_INVALID, "pm_create: null argument");
   if (cfg->abi_version != PM_ABI_VERSION) return fail(nullptr, PM_E_INVALID, "pm_create: ABI version mismatch");
@@ -180,6 +197,7 @@ extern "C" int pm_create(const pm_config *cfg, pm_handle **out) {
   pm_handle *h = new (std::nothrow) pm_handle();
   if (!h) return fail(nullptr, PM_E_NOMEM, "out of memory");
   h->cfg = *cfg;
+  read_knobs(&h->knobs);
   h->alpha.set_raw();
   *out = h;
   return PM_OK;
@@ -381,7 +399,7 @@ static bool seed_eligible(pm_handle *h, std::string *why) {
     pair_ok = pair_ok && p.s.size() >= 20 && p.s.size() <= 32;
     for (unsigned char ch : p.s) pair_ok = pair_ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
   }
-  if (const char *env = getenv("PM_PAIR")) pair_ok = pair_ok && atoi(env) != 0;
+  if (h->knobs.pair >= 0) pair_ok = pair_ok && h->knobs.pair != 0;
   if (sem == PM_SEM_EXACT_BASES && !pair_ok) { *why = "exact_bases runs on the bit-parallel family (the seed family takes it for -K 1 / -K 2 on 20..32 character patterns)"; return false; }
   if ((sem == PM_SEM_FILTER_BITVEC || sem == PM_SEM_EXACT_HALVES) && !pair_ok)
     for (const Pattern &p : h->pats) if (p.esb || p.eeb) { *why = "exact-base constraints need the text-based verify of the bit-parallel family"; return false; }
@@ -491,7 +509,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     if (halves_mode && force_lw > 0 && force_lw <= 10) tile_keys = (size_t)1 << 21;
     // halves of >= 10 bases go through the ranked plan (pm_half_scan): its key bitmap has no capacity either, and a
     // tile of 2^20 halves keeps the "further halves of a key" index inside the slot's 20 bits
-    if (halves_mode && force_lw >= 10 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) {
+    if (halves_mode && force_lw >= 10 && !h->knobs.half_bloom) {
       size_t fits = 0;                                 // seed_build's rule: the ranked plan when >= 90 % of the halves fit its partner test
       for (size_t i = 0; i < sp.size(); ++i) {
         const int L = (int)sp[i].s.size(), plen = (int)partners[i].size();
@@ -499,20 +517,20 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       }
       if (fits * 10 >= sp.size() * 9) tile_keys = (size_t)1 << 20;
     }
-    if (const char *env = getenv("PM_SEED_TILE")) { const long v = atol(env); if (v > 0) tile_keys = (size_t)v; }
+    if (h->knobs.seed_tile > 0) tile_keys = (size_t)h->knobs.seed_tile;
     const size_t ntile = sp.empty() ? 1 : (sp.size() + tile_keys - 1) / tile_keys;
     size_t per = (sp.size() + ntile - 1) / ntile;
     if (halves_mode) per += per & 1;                // keep (left, right) half pairs together: side = index parity
     // Substitution-only search with k = 1, 2 on patterns of 20..32 characters: the pair plan (exact
     // 20-bit key bitmaps, pm_pair.hip) replaces the Bloom-filter plan of pm_seed.hip
     bool use_pair = !halves_mode && !edits_mode && (sk == 1 || sk == 2) && !sp.empty() && force_lw >= 20;
-    if (const char *env = getenv("PM_PAIR")) use_pair = use_pair && atoi(env) != 0;
+    if (h->knobs.pair >= 0) use_pair = use_pair && h->knobs.pair != 0;
     for (size_t ti = 0; ti < ntile && why.empty() && use_pair; ++ti) {
       const size_t lo = ti * per, hi = std::min(sp.size(), lo + per);
       std::vector<Pattern> tp(sp.begin() + lo, sp.begin() + hi);
       std::vector<uint32_t> tid(sid.begin() + lo, sid.begin() + hi);
       PairTables pt;
-      const std::string msg = pair_build(tp, tid, h->alpha, sk, h->eos_code, &pt);
+      const std::string msg = pair_build(tp, tid, h->alpha, sk, h->eos_code, &pt, h->knobs.pair_row);
       if (!msg.empty()) {                                            // not for this set: the seed plan below takes it
         for (PairDevice &d : h->pair) pair_free(&d);
         h->pair.clear();
@@ -521,6 +539,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       }
       h->pair.emplace_back();
       HIP_TRY(h, pair_upload(pt, &h->pair.back(), h->stream));
+      h->pair.back().knobs = h->knobs;
       h->pair.back().viol_level = h->sem == PM_SEM_FILTER_BITVEC ? 3 : 0;   // filter_bitvec chains every candidate; the others drop zone violations
       // the plan facts the rest of this file reads from h->sd (no device tables behind them)
       h->sd.k = sk; h->sd.Lw = 20; h->sd.pb = 5; h->sd.r = 4 - sk; h->sd.ncombos = pt.ncombos; h->sd.ascii = pt.ascii;
@@ -535,12 +554,13 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       if (halves_mode) { tpart.assign(partners.begin() + lo, partners.begin() + hi); tside.assign(sides.begin() + lo, sides.begin() + hi); }
       SeedTables st;
       why = seed_build(tp, tid, h->alpha, sk, h->eos_code, &st, force_lw, halves_mode ? &tpart : nullptr,
-                       halves_mode ? &tside : nullptr, h->cfg.k, edits_mode);
+                       halves_mode ? &tside : nullptr, h->cfg.k, edits_mode, h->knobs);
       if (why.empty() && h->kern == PM_KERNEL_AUTO && st.Lw < (halves_mode ? 8 : 10)) why = "patterns too short for the seed family";
       if (!why.empty()) break;
       SeedDevice *dst = &h->sd;
       if (ti > 0) { h->sd_more.emplace_back(); dst = &h->sd_more.back(); }
       HIP_TRY(h, seed_upload(st, dst, h->stream));
+      dst->knobs = h->knobs;
       dst->maxlen = std::max(dst->maxlen, h->sd.maxlen);
     }
     if (!why.empty()) {
@@ -557,6 +577,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
         std::string msg = bitpar_build(rp, rid, h->alpha, h->scan_k, h->eos_code, &tabs, h->cfg.wildcards != 0, h->cfg.text_n != 0);
         if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine (residue): " + msg);
         HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
+        h->bp.knobs = h->knobs;
       }
       int mx = h->sd.maxlen;
       for (SeedDevice &d : h->sd_more) mx = std::max(mx, d.maxlen);
@@ -602,6 +623,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
                                    h->cfg.wildcards != 0, h->cfg.text_n != 0);
     if (!msg.empty()) return fail(h, PM_E_UNSUPPORTED, "bit-parallel engine: " + msg);
     HIP_TRY(h, bitpar_upload(tabs, h->scan_indels, &h->bp, h->stream));
+    h->bp.knobs = h->knobs;
   }
   if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, sizeof(unsigned long long)));
   if (!h->h_counter) HIP_TRY(h, hipHostMalloc((void **)&h->h_counter, sizeof(unsigned long long), hipHostMallocDefault));
@@ -707,7 +729,7 @@ extern "C" int pm_init(pm_handle *h, const uint8_t *text, int64_t n, const uint8
   const int rc = init_common(h, table, table_len);
   const double ti2 = now_ms();
   if (copier.joinable()) copier.join();
-  if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] init: runtime + stream buffer %.0f ms, tables %.0f ms, then %.0f ms more for the stream upload\n", ti1 - ti0, ti2 - ti1, now_ms() - ti2);
+  if (h->knobs.debug) fprintf(stderr, "[pm] init: runtime + stream buffer %.0f ms, tables %.0f ms, then %.0f ms more for the stream upload\n", ti1 - ti0, ti2 - ti1, now_ms() - ti2);
   if (copy_err != hipSuccess) return fail(h, PM_E_HIP, std::string("pm_init: stream upload: ") + hipGetErrorString(copy_err));
   if (rc) return rc;
   return ensure_packed(h);
@@ -764,8 +786,8 @@ extern "C" int pm_selected_kernel(const pm_handle *h) { return h && h->inited ? 
 extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   if (!h || !buf || !h->inited) return PM_E_INVALID;
   if (h->kern == PM_KERNEL_SEED && !h->pair.empty()) {
-    snprintf(buf, buflen, "kernel=pm_pair_scan tiles=%d combos=%d fields=2-of-4 x 5 bases window=20 chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
-             (int)h->pair.size(), h->pair[0].ncombos, (long long)h->geo.seg_len, h->geo.nseg, h->geo.blocks, h->geo.threads, PAIR_LDS_BYTES);
+    snprintf(buf, buflen, "kernel=pm_pair_scan tiles=%d combos=%d fields=2-of-4 x 5 bases window=20 row_slots=%d chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
+             (int)h->pair.size(), h->pair[0].ncombos, h->pair[0].stride, (long long)h->geo.seg_len, h->geo.nseg, h->geo.blocks, h->geo.threads, PAIR_LDS_BYTES);
     if (h->nrest) {
       const size_t at = strlen(buf);
       if (at < buflen) snprintf(buf + at, buflen - at, " + %s for %zu patterns the seed plan does not take", bitpar_kernel_name(h->scan_k, h->scan_indels), h->nrest);
@@ -1018,8 +1040,13 @@ static int ensure_dp_tables(pm_handle *h) {
   return PM_OK;
 }
 
-extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
-  if (!h || !h->scan_pending) return fail(h, PM_E_INVALID, "pm_scan_wait: no scan in flight");
+// An internal buffer between two kernels of one scan (seed records, suspects) was too small: it has
+// been enlarged and the same range must be scanned again.  That is the library's own business --
+// pm_scan_wait does it -- and never reaches the caller, whose record buffer (pm_set_capacity) was
+// not the problem and must not be reallocated for it.
+static const int SCAN_AGAIN = 1000;
+
+static int scan_wait_once(pm_handle *h, size_t *n_out) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->scan_pending = false;
   (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
@@ -1031,13 +1058,12 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     // the seed buffer of a tile must have held all its seed records
     unsigned long long worst = 0;
     for (int t = 0; t < 1 + (int)h->sd_more.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] %s: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", h->edits_dev ? "edits" : "halves", worst, h->seed_cap, cnt);
+    if (h->knobs.debug) fprintf(stderr, "[pm] %s: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", h->edits_dev ? "edits" : "halves", worst, h->seed_cap, cnt);
     if (worst > h->seed_cap) {                                     // grow the seed buffer and tell the caller to scan again
       (void)hipFree(h->d_seeds); h->d_seeds = nullptr;
       h->seed_cap = (size_t)worst + (size_t)worst / 8 + 1024;
       h->last_count = 0;
-      if (n_out) *n_out = h->cap + 1;                                // "> cap": pm_scan's retry condition
-      return fail(h, PM_E_OVERFLOW, "seed buffer was too small; it has been enlarged, scan the range again");
+      return SCAN_AGAIN;
     }
   }
   if (h->halves_dev) {
@@ -1057,13 +1083,12 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     // the suspect buffer must have held every tile's suspects
     unsigned long long worst = 0;
     for (size_t t = 0; t < h->pair.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] pair plan: %llu suspects (tile with most), capacity %zu, candidates %zu\n", worst, h->susp_cap, cnt);
+    if (h->knobs.debug) fprintf(stderr, "[pm] pair plan: %llu suspects (tile with most), capacity %zu, candidates %zu\n", worst, h->susp_cap, cnt);
     if (worst > h->susp_cap) {                                     // grow it and tell the caller to scan again
       (void)hipFree(h->d_susp); h->d_susp = nullptr;
       h->susp_cap = (size_t)worst + (size_t)worst / 8 + 1024;
       h->last_count = 0;
-      if (n_out) *n_out = std::max<size_t>(cnt, h->cap) + 1;         // "> cap": the callers' grow-and-rescan condition
-      return fail(h, PM_E_OVERFLOW, "suspect buffer was too small; it has been enlarged, scan the range again");
+      return SCAN_AGAIN;
     }
   }
   if (h->edits_dev) {
@@ -1084,7 +1109,7 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last_count = (size_t)h->h_fcounts[0];
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] edits: %zu raw records (with holes) -> %zu unique candidates, dedup %.1f ms\n", tot, h->last_count, now_ms() - td0);
+    if (h->knobs.debug) fprintf(stderr, "[pm] edits: %zu raw records (with holes) -> %zu unique candidates, dedup %.1f ms\n", tot, h->last_count, now_ms() - td0);
     if (n_out) *n_out = h->last_count;
     h->last_launches += 3;
     return PM_OK;
@@ -1096,6 +1121,17 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
     if (n_out) *n_out = h->last_count;
   }
   return PM_OK;
+}
+
+extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
+  if (!h || !h->scan_pending) return fail(h, PM_E_INVALID, "pm_scan_wait: no scan in flight");
+  for (int tries = 0;; ++tries) {
+    const int rc = scan_wait_once(h, n_out);
+    if (rc != SCAN_AGAIN) return rc;
+    if (tries >= 8) return fail(h, PM_E_NOMEM, "pm_scan_wait: the scan's internal record buffers keep overflowing");
+    const int ra = pm_scan_candidates_async(h, h->own_begin, h->own_end);   // the caller's range, with the enlarged buffer
+    if (ra) return ra;
+  }
 }
 
 extern "C" int pm_scan_candidates(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out) {
@@ -1335,7 +1371,7 @@ int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
   }
   for (size_t wi = 0; wi < need_dp.size(); ++wi)
     if (res[wi].ok) outv.push_back(make_hit(res[wi].end, h->pats[need_dp[wi].pid - 1].id, res[wi].value));   // :135
-  if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] filter_bitvec host stage: cluster %.1f ms, windows %.1f ms, %zu DPs %.1f ms\n", tf1 - tf0, tf2 - tf1, need_dp.size(), now_ms() - tf2);
+  if (h->knobs.debug) fprintf(stderr, "[pm] filter_bitvec host stage: cluster %.1f ms, windows %.1f ms, %zu DPs %.1f ms\n", tf1 - tf0, tf2 - tf1, need_dp.size(), now_ms() - tf2);
   return PM_OK;
 }
 
@@ -1704,7 +1740,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));
   if (!extra.empty()) memcpy(out + nfin, extra.data(), extra.size() * sizeof(pm_hit));
   const size_t tot = nfin + extra.size();
-  if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] finalize_device: %zu records, device %.1f ms (%zu finals, %zu left for the host), host part + copies %.1f ms\n", n, tfd1 - tfd0, nfin, nleft, now_ms() - tfd1);
+  if (h->knobs.debug) fprintf(stderr, "[pm] finalize_device: %zu records, device %.1f ms (%zu finals, %zu left for the host), host part + copies %.1f ms\n", n, tfd1 - tfd0, nfin, nleft, now_ms() - tfd1);
   if (flags & PM_FINALIZE_SORTED) sort_hits(out, tot);
   if (n_out) *n_out = tot;
   return PM_OK;

@@ -448,7 +448,7 @@ constexpr int BP_TP_MAX_STRINGS = 32;
 constexpr int64_t BP_TP_SUB = 4096;
 
 static bool bitpar_text_parallel(const BitparDevice &d) {
-  if (const char *env = getenv("PM_BITPAR_TP")) return atoi(env) != 0 && d.nlanes > 0;
+  if (d.knobs.bitpar_tp >= 0) return d.knobs.bitpar_tp != 0 && d.nlanes > 0;
   return d.nlanes > 0 && d.nlanes <= BP_TP_MAX_STRINGS;
 }
 
@@ -458,10 +458,7 @@ ScanGeometry bitpar_geometry(const BitparDevice &d, int64_t begin, int64_t end) 
   if (bitpar_text_parallel(d)) {
     int64_t sub = BP_TP_SUB;
     while (sub > 256 && range / (64 * sub) < 1024) sub >>= 1;      // small ranges: still enough waves
-    if (const char *env = getenv("PM_BITPAR_SEGLEN")) {             // test knob: force tiny runs
-      const int64_t v = atoll(env);
-      if (v >= 16) sub = round_up(v, 16);
-    }
+    if (d.knobs.bitpar_seglen >= 16) sub = round_up((int64_t)d.knobs.bitpar_seglen, 16);   // test knob: force tiny runs
     g.seg_len = 64 * sub;
     const int64_t s_lo = begin / g.seg_len, s_hi = (end - 1) / g.seg_len;
     g.nseg = end > begin ? (int)(s_hi - s_lo + 1) : 0;
@@ -474,10 +471,7 @@ ScanGeometry bitpar_geometry(const BitparDevice &d, int64_t begin, int64_t end) 
   const int64_t target_waves = 32768;
   int64_t seg = round_up(std::max<int64_t>(range * std::max(d.ntiles, 1) / target_waves, 1), BP_BLOCK);
   seg = std::min<int64_t>(std::max<int64_t>(seg, 8192), 1 << 22);
-  if (const char *env = getenv("PM_BITPAR_SEGLEN")) {       // test knob: force tiny segments
-    const int64_t v = atoll(env);
-    if (v >= BP_BLOCK) seg = round_up(v, BP_BLOCK);
-  }
+  if (d.knobs.bitpar_seglen >= BP_BLOCK) seg = round_up((int64_t)d.knobs.bitpar_seglen, BP_BLOCK);   // test knob: force tiny segments
   g.seg_len = seg;
   const int64_t s_lo = begin / seg, s_hi = (end - 1) / seg;
   g.nseg = end > begin ? (int)(s_hi - s_lo + 1) : 0;

@@ -24,6 +24,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -46,6 +47,7 @@ Rccl &rccl() {
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
   r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
   r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
   r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
@@ -104,44 +106,50 @@ extern "C" int pm_comm_create(int device, int rank, int world, const void *id, p
 }
 
 // counts[r] = records rank r contributes (every rank passes the same array: the caller's count
-// exchange came first).  Rank r > 0 sends its n_send = counts[r] records straight out of HBM; rank 0
-// receives them behind its own, in rank order, and copies the whole list to host_out (sum of counts
-// records).  d_send must not be in use by work still running on another stream.
+// exchange came first).  Every rank -- rank 0 included -- sends its n_send = counts[r] records
+// straight out of HBM to rank 0; rank 0 receives them in rank order into one landing buffer and
+// copies the whole list to host_out (sum of counts records).  Rank 0's own records travel as a
+// send/receive to itself inside the same group (RCCL turns that into a device copy), so the exchange
+// is one code path for every world size, the single-GPU one included.  d_send must not be in use by
+// work still running on another stream.  A rank that fails locally aborts the communicator so that
+// its peers' transfers end with an error instead of waiting for it.
 extern "C" int pm_comm_gather(pm_comm *c, const void *d_send, size_t n_send, const uint64_t *counts, pm_hit *host_out) {
   if (!c || !counts || (n_send && !d_send)) return cfail(c, PM_E_INVALID, "pm_comm_gather: bad arguments");
   if (counts[c->rank] != n_send) return cfail(c, PM_E_INVALID, "pm_comm_gather: counts[rank] != n_send");
+  if (!c->comm) return cfail(c, PM_E_INVALID, "pm_comm_gather: the communicator was aborted by an earlier failure");
   Rccl &r = rccl();
+  auto give_up = [&](int code, const std::string &msg) {             // peers must not wait for this rank
+    if (c->comm) { (void)r.CommAbort(c->comm); c->comm = nullptr; }
+    return cfail(c, code, msg);
+  };
   hipError_t e = hipSetDevice(c->device);
-  if (e != hipSuccess) return cfail(c, PM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return give_up(PM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
   size_t total = 0;
   for (int q = 0; q < c->world; ++q) total += (size_t)counts[q];
   if (c->rank == 0) {
-    if (total && !host_out) return cfail(c, PM_E_INVALID, "pm_comm_gather: rank 0 needs host_out");
+    if (total && !host_out) return give_up(PM_E_INVALID, "pm_comm_gather: rank 0 needs host_out");
     if (c->recv_cap < total) {
       if (c->d_recv) (void)hipFree(c->d_recv);
       c->d_recv = nullptr;
       c->recv_cap = total + total / 4 + 1024;
-      if ((e = hipMalloc(&c->d_recv, c->recv_cap * sizeof(pm_hit))) != hipSuccess) return cfail(c, PM_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+      if ((e = hipMalloc(&c->d_recv, c->recv_cap * sizeof(pm_hit))) != hipSuccess) { c->recv_cap = 0; return give_up(PM_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     }
-    if (n_send && (e = hipMemcpyAsync(c->d_recv, d_send, n_send * sizeof(pm_hit), hipMemcpyDeviceToDevice, c->stream)) != hipSuccess)
-      return cfail(c, PM_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
   }
   ncclResult_t rc = r.GroupStart();
-  if (rc != ncclSuccess) return cfail(c, PM_E_HIP, std::string("ncclGroupStart: ") + r.GetErrorString(rc));
+  if (rc != ncclSuccess) return give_up(PM_E_HIP, std::string("ncclGroupStart: ") + r.GetErrorString(rc));
   if (c->rank == 0) {
-    size_t at = (size_t)counts[0];
-    for (int q = 1; q < c->world && rc == ncclSuccess; ++q) {
+    size_t at = 0;
+    for (int q = 0; q < c->world && rc == ncclSuccess; ++q) {
       if (counts[q]) rc = r.Recv(static_cast<char *>(c->d_recv) + at * sizeof(pm_hit), (size_t)counts[q] * sizeof(pm_hit), ncclUint8, q, c->comm, c->stream);
       at += (size_t)counts[q];
     }
-  } else if (n_send) {
-    rc = r.Send(d_send, n_send * sizeof(pm_hit), ncclUint8, 0, c->comm, c->stream);
   }
+  if (n_send && rc == ncclSuccess) rc = r.Send(d_send, n_send * sizeof(pm_hit), ncclUint8, 0, c->comm, c->stream);
   const ncclResult_t rc2 = r.GroupEnd();
-  if (rc != ncclSuccess || rc2 != ncclSuccess) return cfail(c, PM_E_HIP, std::string("RCCL send/recv: ") + r.GetErrorString(rc != ncclSuccess ? rc : rc2));
+  if (rc != ncclSuccess || rc2 != ncclSuccess) return give_up(PM_E_HIP, std::string("RCCL send/recv: ") + r.GetErrorString(rc != ncclSuccess ? rc : rc2));
   if (c->rank == 0 && total && (e = hipMemcpyAsync(host_out, c->d_recv, total * sizeof(pm_hit), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
-    return cfail(c, PM_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
-  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return cfail(c, PM_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return give_up(PM_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return give_up(PM_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
   return PM_OK;
 }
 

@@ -27,6 +27,25 @@ struct Alphabet {
   void set_table(const uint8_t *table, int len);
 };
 
+// Test and measurement knobs (PM_SEED_CHUNK, PM_SEED_GROUP, PM_SEED_DEBUG, PM_SEED_TILE, PM_PAIR, PM_HALF_SCAN,
+// PM_EDIT_SCAN, PM_EDIT_TABLE_LOG, PM_BITPAR_TP, PM_BITPAR_SEGLEN, PM_DEBUG).  The environment is read ONCE, by
+// pm_create (pm_api.cpp read_knobs), into the handle: nothing on the init or launch path calls getenv, and a
+// handle's behaviour does not change when its caller's environment does.  Every field's 0 / -1 / false = unset.
+struct Knobs {
+  long long seed_chunk = 0;          // positions per workgroup of the seed-family scan kernels
+  int seed_group = 0;                // chunks per run of one combo
+  int seed_debug = 0;                // stage switches (measurement builds of the scan kernels)
+  long seed_tile = 0;                // keys per pattern tile
+  int pair = -1;                     // 0: keep -K 1 / -K 2 off the pair plan
+  int pair_row = 0;                  // PM_PAIR_ROW: slots per row of the pair plan's slot table (measurement)
+  bool half_bloom = false;           // exact_halves -k on the round-1 form (PM_HALF_SCAN=bloom)
+  bool edit_bloom = false;           // edits: first stage = the round-1 pm_seed_scan instance (PM_EDIT_SCAN=bloom)
+  int edit_table_log = 0;            // edits: log2 of the key map's bits
+  int bitpar_tp = -1;                // force the text-parallel (1) / tile (0) form of the bit-parallel kernel
+  long long bitpar_seglen = 0;
+  bool debug = false;                // PM_DEBUG: stage timings on stderr
+};
+
 // ---- bit-parallel family (pm_bitpar.hip) -----------------------------------------------------
 constexpr int BP_WPL = 8;          // 32-bit words per lane: a lane holds a 256-bit pattern string
 constexpr int BP_NC = 6;           // distinct stream codes the patterns may accept (A,C,G,T,N + one)
@@ -52,6 +71,7 @@ struct BitparDevice {
   uint8_t  *cmap = nullptr;
   int ntiles = 0, nlanes = 0, k = 0, maxlen = 0;
   bool indels = false;
+  Knobs knobs;                     // set by the caller after bitpar_upload
 };
 
 // Build the packed tables.  Returns "" or an error message (PM_E_UNSUPPORTED).

@@ -20,24 +20,21 @@ namespace pm {
 constexpr int PAIR_THREADS = 1024;                  // 16 waves, one workgroup per CU (LDS bound)
 constexpr int PAIR_WAVES = PAIR_THREADS / 64;
 constexpr int PAIR_MAX_COMBOS = 6;
-constexpr int PAIR_BITMAP_WORDS = 32768;            // 2^20 key bits
-constexpr int PAIR_SUPER = 512;                     // u32 rank before every 2048-bit superblock
-constexpr int PAIR_REL_WORDS = 2048;                // 4096 x u16: rank of a 256-bit block inside its superblock
-constexpr int PAIR_IMAGE_WORDS = PAIR_BITMAP_WORDS + PAIR_SUPER + PAIR_REL_WORDS;   // staged per (combo, chunk)
-constexpr int PAIR_QREGION = 64;                    // per wave: two queue regions of suspicious windows (8-byte entries), one filling, one in flight
-constexpr int PAIR_LDS_BYTES = PAIR_IMAGE_WORDS * 4 + PAIR_WAVES * 2 * PAIR_QREGION * 8;
+constexpr int PAIR_BITMAP_WORDS = 32768;            // 2^20 key bits: key bits 0..14 = row (dword), 15..19 = bit
+constexpr int PAIR_QUEUE = 128;                     // per wave: suspect records (16 bytes) waiting to leave in a batch
+constexpr int PAIR_LDS_BYTES = PAIR_BITMAP_WORDS * 4 + PAIR_WAVES * PAIR_QUEUE * 16;   // key bitmap + the waves' suspect queues
 static_assert(PAIR_LDS_BYTES <= 163840, "160 KiB of LDS per workgroup");
 
 struct PairTables {                                 // one pattern tile
-  int k = 0, maxlen = 0, ncombos = 0, eos_code = -1;
+  int k = 0, maxlen = 0, ncombos = 0, eos_code = -1, stride = 0;
   bool ascii = false;
   int fa[PAIR_MAX_COMBOS] = {}, fb[PAIR_MAX_COMBOS] = {};   // key fields of every combo (a < b), the other two are (c < d)
-  std::vector<uint32_t> image;                      // [combo][PAIR_IMAGE_WORDS]
-  std::vector<uint32_t> entries;                    // [combo][2 * distinct keys]: see pm_pair.hip
-  std::vector<int16_t> direct;                      // [combo][2^20]: direct-mapped by key, six bases of the first pattern | -(k+1) or -8 (several) in the top four bits
-  std::vector<uint32_t> first_pat;                  // [combo][distinct keys + 1]: first index into order[] of every key
+  std::vector<uint32_t> image;                      // [combo][PAIR_BITMAP_WORDS]
+  std::vector<uint64_t> slots;                      // [combo][PAIR_BITMAP_WORDS * stride]: slot (row, rank of the key inside its row), see pm_pair.hip slot_pack
+  std::vector<uint32_t> row_base;                   // [combo][PAIR_BITMAP_WORDS + 1]: keys that occur in front of every row (rank of a key = row_base[row] + rank in row)
+  std::vector<uint32_t> first_pat;                  // [combo][distinct keys + 1]: by rank, first index into order[] of every key
   std::vector<uint32_t> order;                      // [combo][np]: pattern indices sorted by key
-  size_t entries_off[PAIR_MAX_COMBOS] = {}, first_off[PAIR_MAX_COMBOS] = {};   // per combo, in elements of the arrays above
+  size_t first_off[PAIR_MAX_COMBOS] = {};           // per combo, in elements of first_pat
   std::vector<uint64_t> pat40;                      // last 20 bases, 2 bits each
   std::vector<uint8_t> pat_len;
   std::vector<uint32_t> pat_id;
@@ -46,22 +43,24 @@ struct PairTables {                                 // one pattern tile
 };
 
 struct PairDevice {
-  int k = 0, maxlen = 0, ncombos = 0, eos_code = -1;
+  int k = 0, maxlen = 0, ncombos = 0, eos_code = -1, stride = 0;
   bool ascii = false;
   int fa[PAIR_MAX_COMBOS] = {}, fb[PAIR_MAX_COMBOS] = {};
-  size_t entries_off[PAIR_MAX_COMBOS] = {}, first_off[PAIR_MAX_COMBOS] = {};
+  size_t first_off[PAIR_MAX_COMBOS] = {};
   size_t np = 0;
-  int16_t *direct = nullptr;
-  uint32_t *image = nullptr, *entries = nullptr, *first_pat = nullptr, *order = nullptr, *pat_id = nullptr;
+  uint64_t *slots = nullptr;
+  uint32_t *image = nullptr, *row_base = nullptr, *first_pat = nullptr, *order = nullptr, *pat_id = nullptr;
   uint64_t *pat40 = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr;
   uint32_t *pat_zone = nullptr;
   int viol_level = 0;                                 // see PairArgs::viol_level (set by the caller after pair_upload)
+  Knobs knobs;                                        // likewise
 };
 
 // "" or why the plan does not take this pattern set
+// stride_knob: slots per row of the slot table (0 = default)
 std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids, const Alphabet &alpha, int k,
-                       int eos_code, PairTables *out);
+                       int eos_code, PairTables *out, int stride_knob = 0);
 hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st);
 void pair_free(PairDevice *d);
 ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end);

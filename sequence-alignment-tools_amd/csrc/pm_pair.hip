@@ -1,5 +1,5 @@
-// pm_pair.hip -- "pair plan" scan kernels for gfx950: exact 20-bit key bitmap in LDS, a direct-mapped
-// 2-byte table in L2 for the keys that occur, rank-indexed exact table for the few windows left.
+// pm_pair.hip -- "pair plan" scan kernels for gfx950: exact 20-bit key bitmap in LDS, and ONE 8-byte
+// lookup in an L2-resident slot table that settles a key hit.
 //
 // What it computes: every (end, pattern, d) with d = Hamming(stream window, pattern) <= k, k = 1 or 2,
 // and no EOS inside the window -- the candidate set of the reference's substitution-only k-error
@@ -11,34 +11,35 @@
 // leave >= 2 fields untouched: the window agrees with the pattern on one of the 6 field pairs
 // (k = 1: on fields {0,1} or {2,3}).  A field pair is a 20-bit key, and 2^20 key bits are exactly a
 // 128 KiB bitmap:
-//   * a WORKGROUP owns one (field pair, stream chunk): it stages that pair's key bitmap (and a rank
-//     directory over it) in LDS, then streams its chunk of the 2-bit packed stream;
+//   * a WORKGROUP owns one (field pair, stream chunk): it stages that pair's key bitmap in LDS (key
+//     bits 0..14 = ROW = dword, bits 15..19 = bit), then streams its chunk of the 2-bit packed stream;
 //   * a LANE owns 16 consecutive window positions per block of 1024; its two predecessors' dwords
 //     come in by two whole-wave DPP shifts.  Everything that runs for every window is straight-line
 //     code with compile-time window offsets:
-//       test     one v_alignbit (the key, pre-shifted by 2; field pairs that are apart: a second one
-//                and a v_bfi), one v_and (LDS byte address: key bits 0..14 select the word), one
-//                ds_read_b32, two shifts (key bits 15..19 select the bit; verdict funnelled into a
-//                16-bit mask), then one 2-byte load from the pair's direct-mapped table in L2 (2 MiB,
-//                index = key): six bases of the first pattern that has the key and a "several patterns
-//                share this key" bit.  Windows whose key does not occur (83 % at 200k patterns) read
-//                entry 0 -- one cached line for all of them -- so the load needs no branch;
-//       consume  one block later, when the loads have landed: XOR + popcount of those six bases
-//                against the window's other fields.  ~2 % of the windows stay suspicious;
-//   * those are compacted per wave (ballot + mbcnt) into an LDS queue and resolved 64 at a time: the
-//     key's RANK among the set bits of the bitmap (two-level directory + popcounts, all in LDS)
-//     indexes a dense table with one 8-byte slot per distinct key -- the other 20 window bits of up
-//     to three patterns -- whose load is consumed one batch later (XOR + popcount on all 20 bits);
-//   * what is still within k there (1e-3 of the positions) goes to a suspect list; a second kernel,
-//     pm_pair_verify, reads the raw stream bytes for the exact distance (N = mismatch, EOS = reject)
-//     with every lane busy;
+//       test     key (one or two v_alignbit + v_bfi), one ds_read_b32 of the key's row.  The row
+//                gives the key's bit AND, for free, its rank inside the row (popcount of the lower
+//                bits): the keys that occur own consecutive 8-byte slots of a table in L2 -- `stride`
+//                slots per row -- so (row, rank in row) addresses the key's slot without any rank
+//                directory: one global_load_dwordx2 per window, branch-free (windows whose key does
+//                not occur, 83 % at 200k patterns, read a slot of row 0: one cached line);
+//       consume  one block later, when the loads have landed: the slot holds the OTHER 20 window bits
+//                of up to three patterns with this key; three XOR + popcount against the window's own
+//                other fields decide the window.  What survives is a true candidate on the packed
+//                bases (1e-3 of the positions), a key with more than three patterns, or a key beyond
+//                its row's slots (0.3 % of the keys at 200k patterns: row occupancy is Poisson);
+//   * those few go -- by a divergent path that recomputes what it needs -- to a suspect list; a second
+//     kernel, pm_pair_verify, reads the raw stream bytes for the exact distance (N = mismatch, EOS =
+//     reject) with every lane busy;
 //   * a (window, pattern) pair that agrees on several field pairs is reported by the first of them
 //     in the plan's list.
 //
-// Bounds (3 Gbp, 200k patterns, k = 2; PM_SEED_DEBUG stage switches, scripts/pair_stages.sh): the
-// straight-line part is LDS-bank-conflict and VALU bound (8.5 ms for 1.8e10 tests: 5 + 4 + 9 VALU per
-// test, random ds_read_b32 ~7 cycles per wave instruction), the 3.1e9 direct-table lookups add 4.9 ms
-// (the L1 fill path moves one 128-byte line per lookup), the suspicious 2 % another 4 ms.
+// What bounds it (3 Gbp, 200k patterns, k = 2; scripts/probe/tcp_gather.hip, profiles/): every key hit
+// (17.4 % of 1.8e10 tests) is a random 128-byte line from L2 into a CU's L1, and that path moves one
+// line per ~2 cycles and CU -- 269 G lines/s for the chip = the 34 TB/s of L2 bandwidth -- whatever
+// the bytes asked for: 3.1e9 lines = 11.5 ms.  Round 2's form of this kernel paid a second such line
+// (rank-indexed exact table) for the 2.3 % of the windows its 2-byte direct table could not settle,
+// plus the rank directory, a wave queue and the compaction in front of it; here a key hit costs
+// exactly one line.
 #include "pm_internal.h"
 #include "pm_pair.h"
 
@@ -52,17 +53,16 @@ namespace pm {
 namespace {
 
 constexpr int WAVES = PAIR_WAVES;
-constexpr uint32_t SUPER_OFF = PAIR_BITMAP_WORDS * 4;                 // LDS byte offsets; the bitmap sits at LDS address 0
-constexpr uint32_t REL_OFF = SUPER_OFF + PAIR_SUPER * 4;
-constexpr uint32_t WAVE_OFF = PAIR_IMAGE_WORDS * 4;
-constexpr uint32_t WAVE_BYTES = 2 * PAIR_QREGION * 8;
 constexpr uint32_t F20 = 0xfffffu;
-constexpr int PAIR_SUSPECT_BLOCK = 16;                               // suspect slots a wave reserves per atomic
 constexpr uint32_t PAIR_SUSPECT_HOLE = 0xffffffffu;                  // rank field of a reserved slot that stayed unused
-// Exact table, one 8-byte slot per distinct key: the other 20 window bits of up to three patterns that
-// have the key (o1 | o2 << 20 | o3 << 40) and, in bits 60..63, how many there are (4 = more than three).
-__device__ __host__ __forceinline__ uint64_t slot_pack(uint32_t o1, uint32_t o2, uint32_t o3, uint32_t count) {
-  return (uint64_t)o1 | ((uint64_t)o2 << 20) | ((uint64_t)o3 << 40) | ((uint64_t)(count > 4 ? 4 : count) << 60);
+constexpr uint32_t WHAT_REST = 8u, WHAT_ALL = 16u;                   // suspect: walk the key's patterns from the fourth / from the first
+// Slot of a key, 8 bytes: the other 20 window bits of up to three patterns that have the key
+// (o1 | o2 << 20 | o3 << 40; with fewer than three patterns the free fields repeat o1) and bit 63 =
+// "not settled by these three": more patterns share the key, or -- last slot of every row -- the key
+// lies beyond its row's slots.  Bits 60..62 are zero: the top nibble, sign-extended, is 0 or -8 and
+// goes straight into the consume stage's mismatch count.
+__device__ __host__ __forceinline__ uint64_t slot_pack(uint32_t o1, uint32_t o2, uint32_t o3, bool walk) {
+  return (uint64_t)o1 | ((uint64_t)o2 << 20) | ((uint64_t)o3 << 40) | ((uint64_t)(walk ? 8 : 0) << 60);
 }
 
 struct PairArgs {
@@ -73,12 +73,13 @@ struct PairArgs {
   int64_t chunk0, chunk_len;            // first chunk index (absolute), positions per workgroup
   int nchunks, ncombos, group;
   int k, eos_code, debug;
+  int stride;                           // slots per row of the slot table (the last one is the row's overflow marker)
   int fa[PAIR_MAX_COMBOS], fb[PAIR_MAX_COMBOS];
-  const uint32_t *image;                // [combo][PAIR_IMAGE_WORDS]
-  const int16_t *direct;                // [combo][2^20]: direct-mapped by key, see pair_build
-  const uint2 *entries;                 // all combos; combo c starts at entries_off[c]
-  const uint32_t *first_pat, *order;
-  uint32_t entries_off[PAIR_MAX_COMBOS], first_off[PAIR_MAX_COMBOS];
+  const uint32_t *image;                // [combo][PAIR_BITMAP_WORDS]: key bitmap
+  const uint2 *slots;                   // [combo][PAIR_BITMAP_WORDS * stride]
+  const uint32_t *row_base;             // [combo][PAIR_BITMAP_WORDS + 1]: distinct keys in front of every row
+  const uint32_t *first_pat, *order;    // [combo][distinct keys + 1] (by rank), [combo][np]: patterns sorted by key
+  uint32_t first_off[PAIR_MAX_COMBOS];
   uint32_t np;
   const uint2 *pat40;
   const uint8_t *pat_len;
@@ -90,21 +91,17 @@ struct PairArgs {
   pm_hit *out;
   unsigned long long *counter;
   unsigned long long cap;
-  uint4 *susp;                          // suspect records for pm_pair_verify: {rank, other fields, position | combo << 40 | what << 44}
+  uint4 *susp;                          // suspect records for pm_pair_verify: {key, other fields, position | combo << 40}
   unsigned long long *susp_count;
   unsigned long long susp_cap;
 };
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u128;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) u32x2 lds_u64;
-__device__ __forceinline__ lds_u32 *lds32(uint32_t addr) { return reinterpret_cast<lds_u32 *>((uintptr_t)addr); }
-__device__ __forceinline__ lds_u16 *lds16(uint32_t addr) { return reinterpret_cast<lds_u16 *>((uintptr_t)addr); }
+typedef __attribute__((address_space(3))) u32x4 lds_u128;
 __device__ __forceinline__ lds_u128 *lds128(uint32_t addr) { return reinterpret_cast<lds_u128 *>((uintptr_t)addr); }
-__device__ __forceinline__ lds_u64 *lds64(uint32_t addr) { return reinterpret_cast<lds_u64 *>((uintptr_t)addr); }
+__device__ __forceinline__ lds_u32 *lds32(uint32_t addr) { return reinterpret_cast<lds_u32 *>((uintptr_t)addr); }
 
 __device__ __forceinline__ uint32_t load_packed(const uint32_t *packed, int64_t npacked, int64_t pos) {
   const int64_t i = pos >> 4;
@@ -145,10 +142,11 @@ __device__ __host__ __forceinline__ void other_fields(int a, int b, int *c, int 
 // and are within k substitutions on the rest of the packed window; count mismatches on the raw stream
 // codes over the whole pattern (N = mismatch, EOS = reject) and report -- once: only through the first
 // combo of the plan whose two fields are clean.
-__device__ __forceinline__ void pair_verify(const PairArgs &a, int combo, int64_t p, uint32_t pi) {
+// Returns whether (p, pi) is a candidate this combo reports; *hh is then its record.
+__device__ __forceinline__ bool pair_verify(const PairArgs &a, int combo, int64_t p, uint32_t pi, pm_hit *hh) {
   const int L = a.pat_len[pi];
   const int64_t start = p + 1 - L;
-  if (start < 0) return;
+  if (start < 0) return false;
   // all 32 pattern codes and the 32 stream bytes from `start` at once (every load independent of the
   // others: this kernel is a chain of dependent loads as it is), per-byte verdicts by SWAR
   const uint4 *pcv = reinterpret_cast<const uint4 *>(a.pat_codes + (size_t)pi * 32);
@@ -179,13 +177,13 @@ __device__ __forceinline__ void pair_verify(const PairArgs &a, int combo, int64_
   }
   const uint32_t lenmask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
   mism &= lenmask;
-  if (a.eos_code >= 0 && (eos & lenmask)) return;     // EOS inside the window: never a candidate
+  if (a.eos_code >= 0 && (eos & lenmask)) return false;   // EOS inside the window: never a candidate
   int ham = __popc(mism);                             // N (or any other code) = mismatch
-  if (ham > a.k) return;
+  if (ham > a.k) return false;
   // exact-base constraints (pattern_alignment.cc:320-323: a substitution inside an exact zone is a
   // constraint violation, the verify fails)
   if (mism & a.pat_zone[pi]) {
-    if (a.viol_level <= 0) return;
+    if (a.viol_level <= 0) return false;
     ham = a.viol_level;
   }
   const uint32_t tail = mism >> (L - 20);             // the 20 bases the plan looks at
@@ -195,36 +193,54 @@ __device__ __forceinline__ void pair_verify(const PairArgs &a, int combo, int64_
   int first = -1;
   for (int c = 0; c < a.ncombos && first < 0; ++c)
     if (!((dirty >> a.fa[c]) & 1u) && !((dirty >> a.fb[c]) & 1u)) first = c;
-  if (first != combo) return;
+  if (first != combo) return false;
   const int half = L / 2;
   const bool left_clean = (mism & ((1u << half) - 1u)) == 0, right_clean = (mism >> half) == 0;
-  const unsigned long long o = atomicAdd(a.counter, 1ull);
-  if (o < a.cap) {
-    pm_hit hh;
-    hh.end = p + 1; hh.pid = a.pat_id[pi]; hh.k = (uint8_t)ham;
-    hh.aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh.aux[1] = hh.aux[2] = 0;
-    a.out[o] = hh;
+  hh->end = p + 1; hh->pid = a.pat_id[pi]; hh->k = (uint8_t)ham;
+  hh->aux[0] = (uint8_t)((left_clean ? 1 : 0) | (right_clean ? 2 : 0)); hh->aux[1] = hh->aux[2] = 0;
+  return true;
+}
+
+// Append the records of the lanes that have one (`ok`; called by whichever lanes of the wave are
+// executing together): one atomic per wave and call -- the first lane with a record reserves the slots
+// of all of them -- instead of one per record on the single shared counter (same-address atomics
+// serialise at ~2.5 ns each; 10^6 records per launch).
+__device__ __forceinline__ void pair_emit(const PairArgs &a, bool ok, const pm_hit &hh) {
+  const unsigned long long bal = __ballot(ok);
+  if (bal == 0) return;
+  const int leader = __ffsll((long long)bal) - 1;
+  const int lane = threadIdx.x & 63;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)__popcll(bal));
+  const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+  if (ok) {
+    const unsigned long long o = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+    if (o < a.cap) a.out[o] = hh;
   }
 }
 
-// A suspect: a window whose exact-table slot says "within k on the other fields" for the key's first /
-// second / third pattern (what & 1, 2, 4), or that the key has more than three (what & 8: walk the
-// rest of the key's run of the sorted pattern list).
+// A suspect: a window whose slot says "within k on the other fields" for the key's first / second /
+// third pattern (what & 1, 2, 4), that the key has more than three (WHAT_REST: walk the rest of the
+// key's run of the sorted pattern list), or whose key has no slot (WHAT_ALL: walk the whole run).
 __device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint32_t rank, uint32_t what, uint32_t wo, int64_t p) {
   const uint32_t *fp = a.first_pat + a.first_off[combo];
   const uint32_t *ord = a.order + (size_t)combo * a.np;
-  const uint32_t t0 = fp[rank];
-  for (uint32_t j = 0; j < 3; ++j)
-    if ((what >> j) & 1u) pair_verify(a, combo, p, ord[t0 + j]);
-  if (what & 8u) {
+  const uint32_t t0 = fp[rank], t1 = fp[rank + 1];
+  pm_hit hh;
+  for (uint32_t j = 0; j < 3; ++j) {
+    const bool ok = ((what >> j) & 1u) && t0 + j < t1 && pair_verify(a, combo, p, ord[t0 + j], &hh);   // (free slot fields repeat the first pattern)
+    pair_emit(a, ok, hh);
+  }
+  if (what & (WHAT_REST | WHAT_ALL)) {
     int c, d;
     other_fields(a.fa[combo], a.fb[combo], &c, &d);
-    for (uint32_t t = t0 + 3; t < fp[rank + 1]; ++t) {
+    for (uint32_t t = t0 + ((what & WHAT_ALL) ? 0u : 3u); t < t1; ++t) {
       const uint32_t pi = ord[t];
       const uint2 pp = a.pat40[pi];
       const uint64_t W = ((uint64_t)pp.y << 32) | pp.x;
       const uint32_t po = field_of(W, c) | (field_of(W, d) << 10);
-      if (sym_distance(po ^ wo) <= a.k) pair_verify(a, combo, p, pi);
+      const bool ok = sym_distance(po ^ wo) <= a.k && pair_verify(a, combo, p, pi, &hh);
+      pair_emit(a, ok, hh);
     }
   }
 }
@@ -241,24 +257,36 @@ __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
     const uint4 r = a.susp[i];
     if (r.x == PAIR_SUSPECT_HOLE) continue;
     const uint64_t pw = ((uint64_t)r.w << 32) | r.z;
-    pair_resolve(a, (int)((pw >> 40) & 7u), r.x, (uint32_t)(pw >> 44) & 15u, r.y, (int64_t)(pw & 0xffffffffffull));
+    const int combo = (int)((pw >> 40) & 7u);
+    // the key's row of the bitmap (global copy) -> rank; its slot -> which of its patterns are within k on the other fields
+    const uint32_t key = r.x, wo = r.y, row = key & 0x7fffu, bit = key >> 15;
+    const uint32_t wd = a.image[(size_t)combo * PAIR_BITMAP_WORDS + row];
+    if (!((wd >> bit) & 1u)) continue;
+    const uint32_t lr = (uint32_t)__popc(wd & ((1u << bit) - 1u));
+    const uint32_t rank = a.row_base[(size_t)combo * (PAIR_BITMAP_WORDS + 1) + row] + lr;
+    uint32_t what = WHAT_ALL;
+    if (lr < (uint32_t)a.stride - 1u) {
+      const uint2 sl = a.slots[((size_t)combo * PAIR_BITMAP_WORDS + row) * (size_t)a.stride + lr];
+      const uint64_t S = ((uint64_t)sl.y << 32) | sl.x;
+      what = (sym_distance(((uint32_t)S ^ wo) & F20) <= a.k ? 1u : 0u) | (sym_distance(((uint32_t)(S >> 20) ^ wo) & F20) <= a.k ? 2u : 0u) |
+             (sym_distance(((uint32_t)(S >> 40) ^ wo) & F20) <= a.k ? 4u : 0u) | ((sl.y >> 31) ? WHAT_REST : 0u);
+    }
+    pair_resolve(a, combo, rank, what, wo, (int64_t)(pw & 0xffffffffffull));
   }
 }
 
 // One (field pair, chunk) of the scan.  A, B: key fields (compile time: every window offset is an
 // immediate).  See the file comment for the stages.
 //
-// Per block of 1024 positions (16 per lane) a wave runs three things, all but the last as straight,
-// branch-free code over the lane's 16 windows:
-//   test     key -> LDS bitmap bit (5 VALU + 1 ds_read_b32), then one 2-byte load per window from the
-//            pair's direct-mapped table in L2 (index = key; windows whose key is absent read entry 0,
-//            one cached line for all of them, so the load needs no branch and no exec juggling);
-//   consume  (one block later, when those loads have landed) six bases of the first pattern that has
-//            the key against the window's other fields, plus the entry's "several patterns share
-//            this key" bit: only ~2 % of the windows stay suspicious;
-//   resolve  those few are compacted (ballot + mbcnt) into a wave queue and resolved by whole waves:
-//            rank of the key in the bitmap -> 8-byte entry with the other 20 bits of up to two
-//            patterns -> XOR + popcount -> raw stream bytes for the exact distance.
+// Per block of 1024 positions (16 per lane) a wave runs, as straight branch-free code over the lane's
+// 16 windows:
+//   test     key -> the key's row of the LDS bitmap (1 ds_read_b32) -> bit, rank inside the row ->
+//            one 8-byte load of the key's slot from the pair's table in L2 (windows whose key is
+//            absent read a slot of row 0: one cached line, so the load needs no branch);
+//   consume  (one block later, when those loads have landed) the slot's three patterns against the
+//            window's other 20 bits: sign of min(substitutions) - (k + 1), the slot's "walk" flag folded
+//            into the third count.
+// What is left after that (1e-3 of the windows) takes the divergent path `emit`.
 template <int A, int B>
 __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int combo, const int cj) {
   constexpr int C = (A != 0 && B != 0) ? 0 : ((A != 1 && B != 1) ? 1 : 2);
@@ -266,7 +294,6 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   static_assert(A < B && C < D && C != A && C != B && D != A && D != B, "fields");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t QB = WAVE_OFF + (uint32_t)wave * WAVE_BYTES;       // this wave's queue of suspicious windows (8-byte entries)
   const int64_t sub = a.chunk_len / WAVES;
   const int64_t ws = (a.chunk0 + cj) * a.chunk_len + (int64_t)wave * sub;   // first position (window's last base) of this wave
   int64_t own_lo = ws > a.begin ? ws : a.begin;
@@ -276,8 +303,9 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   if (own_lo < 19) own_lo = 19;                                   // the 20-base window must fit in the stream
   if (own_lo >= own_hi) return;
 
-  const uint2 *entries = a.entries + a.entries_off[combo];
-  const int16_t *direct = a.direct + ((size_t)combo << 20);
+  const uint32_t stride = (uint32_t)a.stride, kmax = stride - 1u;   // slots per row; rank of a row's overflow marker
+  const uint32_t rowmul = 2u * stride;                              // slot bytes per row / 4 (the row comes as row * 4)
+  const char *slots = reinterpret_cast<const char *>(a.slots + (size_t)combo * PAIR_BITMAP_WORDS * stride);
   // the 32 bases in front of the wave's range (wave-uniform; they enter lanes 0 and 1 through the DPP shifts)
   uint32_t carry1, carry2;
   {
@@ -285,83 +313,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     carry2 = __builtin_amdgcn_readlane(pk, 0);
     carry1 = __builtin_amdgcn_readlane(pk, 1);
   }
-
-  // The queue of suspicious windows has two regions of 64 entries {window low word, window bits
-  // 32..39 | position << 8}: one fills up while the exact-table loads of the other are in flight.
-  int qn = 0, pcount = 0;                                         // wave-uniform: fill of the filling region, entries of the one in flight
-  uint32_t qr = 0;                                                // wave-uniform: region being filled
-  uint32_t pex = 0, pey = 0, prank = 0;                           // the lane's lookup in flight
-  unsigned long long sb_next = 0;                                 // wave-uniform: reserved suspect slots not yet used
-  int sb_left = 0;
-
-  // the region in flight: its loads have landed -- XOR + popcount against the window's other fields
-  auto finish = [&]() __attribute__((always_inline)) {
-    if (pcount == 0) return;
-    const bool on = lane < pcount;
-    const u32x2 e = *lds64(QB + (qr ^ 1u) * (PAIR_QREGION * 8) + 8 * lane);
-    const uint64_t W = ((uint64_t)(e.y & 0xffu) << 32) | e.x;
-    const uint32_t wo = field_of(W, C) | (field_of(W, D) << 10);
-    const uint64_t S = ((uint64_t)pey << 32) | pex;
-    const uint32_t cnt = pey >> 28;
-    const bool hit1 = sym_distance(((uint32_t)S ^ wo) & F20) <= a.k;
-    const bool hit2 = cnt >= 2 && sym_distance(((uint32_t)(S >> 20) ^ wo) & F20) <= a.k;
-    const bool hit3 = cnt >= 3 && sym_distance(((uint32_t)(S >> 40) ^ wo) & F20) <= a.k;
-    const uint32_t what = on ? ((hit1 ? 1u : 0u) | (hit2 ? 2u : 0u) | (hit3 ? 4u : 0u) | (cnt >= 4 ? 8u : 0u)) : 0u;
-    pcount = 0;
-    const unsigned long long bal = __ballot(what != 0);
-    if (bal == 0) return;
-    // suspects go to a list for the verify kernel.  Slots are reserved PAIR_SUSPECT_BLOCK at a time per
-    // wave: one atomic per suspect batch on the one shared counter serialises the chip (same-address
-    // atomics take ~2.5 ns each: 2 million of them cost 6 ms here).  Unused slots are marked as holes.
-    const int c = __popcll(bal);
-    const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-    int done = 0;                                                   // wave-uniform: suspects of this batch already placed
-    while (done < c) {
-      if (sb_left == 0) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.susp_count, (unsigned long long)PAIR_SUSPECT_BLOCK);
-        sb_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
-        sb_left = PAIR_SUSPECT_BLOCK;
-      }
-      const int take = c - done < sb_left ? c - done : sb_left;
-      if (what && before >= done && before < done + take) {
-        const unsigned long long slot = sb_next + (unsigned long long)(before - done);
-        const uint64_t pw = (uint64_t)(ws + (e.y >> 8)) | ((uint64_t)combo << 40) | ((uint64_t)what << 44);
-        if (slot < a.susp_cap) a.susp[slot] = make_uint4(prank, wo, (uint32_t)pw, (uint32_t)(pw >> 32));
-      }
-      sb_next += take; sb_left -= take; done += take;
-    }
-  };
-  // the region just filled: rank every key, start the exact table's loads
-  auto issue = [&]() __attribute__((always_inline)) {
-    if (lane >= qn) return;
-    const u32x2 e = *lds64(QB + qr * (PAIR_QREGION * 8) + 8 * lane);
-    const uint64_t W = ((uint64_t)(e.y & 0xffu) << 32) | e.x;
-    const uint32_t key = field_of(W, A) | (field_of(W, B) << 10);
-    // rank of the key among the set bits: superblock (2048 bits) + block (256 bits) + words + bit
-    const uint32_t word = key & 0x7fffu, bit = key >> 15;
-    const uint32_t sup = *lds32(SUPER_OFF + ((word >> 6) << 2));
-    const uint32_t rel = *lds16(REL_OFF + ((word >> 3) << 1));
-    const u32x4 b0 = *lds128((word >> 3) << 5), b1 = *lds128(((word >> 3) << 5) + 16);
-    const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    const uint32_t wq = word & 7u;
-    uint32_t cnt = sup + rel, part = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < 8; ++t) {
-      cnt += t < wq ? (uint32_t)__popc(bw[t]) : 0u;
-      part = t == wq ? bw[t] : part;
-    }
-    prank = cnt + __popc(__builtin_amdgcn_ubfe(part, 0, bit));
-    if (a.debug & 2) { pex = prank; pey = key; return; }           // measurement: everything but the table load
-    const uint2 ent = entries[prank];
-    pex = ent.x; pey = ent.y;
-  };
-  auto drain = [&]() __attribute__((always_inline)) {
-    if (a.debug & 1) { qn = 0; return; }
-    finish();
-    issue();
-    pcount = qn; qr ^= 1u; qn = 0;
-  };
+  const uint32_t QB = PAIR_BITMAP_WORDS * 4 + (uint32_t)wave * (PAIR_QUEUE * 16);   // this wave's suspect queue (16-byte entries) behind the bitmap
+  int qn = 0;                                                     // wave-uniform: entries in it
 
   // four blocks of 1024 bases (one packed dword per lane each) in flight per wave
   uint32_t q0 = load_packed(a.packed, a.npacked, ws + 16 * lane);
@@ -369,16 +322,18 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t q2 = ws + 2048 < own_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
   uint32_t q3 = ws + 3072 < own_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
 
-  const uint32_t m555 = 0x555u, moff = 0x1ffffeu;                  // (v_bitop3 takes no literal: constants in SGPRs)
+  const uint32_t m5 = 0x55555u;                                    // (v_bitop3 takes no literal: constants in SGPRs)
+  const int negk1 = -(a.k + 1);
+
   // consume stage of half a block (windows 8H .. 8H+7 of the block whose stream words are v2 : v1 : vc):
-  // its table entries E have landed.  Returns the suspicious windows, bit j = window 8H + j.
-  auto consume = [&](auto HALF, uint32_t v2, uint32_t v1, uint32_t vc, const int32_t (&E)[8]) __attribute__((always_inline)) -> uint32_t {
+  // its slots E have landed.  Returns the suspicious windows, bit j = window 8H + j.
+  auto consume = [&](auto HALF, uint32_t v2, uint32_t v1, uint32_t vc, const u32x2 (&E)[8]) __attribute__((always_inline)) -> uint32_t {
     constexpr int H = decltype(HALF)::value;
     uint32_t sacc = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int i = 8 * H + j;
-      uint32_t w = 0;                                               // six bases of the window's other fields at bits 0..11
+      uint32_t w = 0;                                               // the window's other fields: C at bits 0..9, D at bits 10..19 (bits above: anything)
 #define PM_PAIR_OTHER(I)                                                                                        \
       if (i == I) {                                                                                                 \
         const uint32_t X = bits_at<2 * I + 26 + 10 * C>(v2, v1, vc);                                                \
@@ -388,43 +343,62 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       PM_PAIR_OTHER(0) PM_PAIR_OTHER(1) PM_PAIR_OTHER(2) PM_PAIR_OTHER(3) PM_PAIR_OTHER(4) PM_PAIR_OTHER(5) PM_PAIR_OTHER(6) PM_PAIR_OTHER(7)
       PM_PAIR_OTHER(8) PM_PAIR_OTHER(9) PM_PAIR_OTHER(10) PM_PAIR_OTHER(11) PM_PAIR_OTHER(12) PM_PAIR_OTHER(13) PM_PAIR_OTHER(14) PM_PAIR_OTHER(15)
 #undef PM_PAIR_OTHER
-      const uint32_t x = (uint32_t)E[j] ^ w;
-      // substitutions on the six bases, minus k + 1 (the entry's top four bits, sign-extended: -(k+1), or
-      // -8 when several patterns share the key): negative = suspicious; the sign bits are funnelled
-      // into sacc (v_bitop3 (a | b) & c, v_bcnt with accumulator, v_alignbit: no compare)
-      const int z = __popc(__builtin_amdgcn_bitop3_b32(x, x >> 1, m555, 0xa8)) + (E[j] >> 12);
+      // substitutions against each of the slot's three patterns, minus k + 1; the slot's top nibble
+      // (0 or -8: "walk") is added to the third count: negative minimum = suspicious.  Per pattern
+      // XOR, shift, (a | b) & 0x55555 (the mask also drops the bits above the 20), popcount.
+      const uint32_t x1 = E[j].x ^ w, x2 = __builtin_amdgcn_alignbit(E[j].y, E[j].x, 20) ^ w, x3 = (E[j].y >> 8) ^ w;
+      const int d1 = __popc(__builtin_amdgcn_bitop3_b32(x1, x1 >> 1, m5, 0xa8)) + negk1;
+      const int d2 = __popc(__builtin_amdgcn_bitop3_b32(x2, x2 >> 1, m5, 0xa8)) + negk1;
+      const int d3 = __popc(__builtin_amdgcn_bitop3_b32(x3, x3 >> 1, m5, 0xa8)) + (((int)E[j].y >> 28) + negk1);
+      const int z = min(d1, min(d2, d3));
       sacc = __builtin_amdgcn_alignbit(sacc, (uint32_t)z, 31);
     }
     return __brev(sacc) >> 24;
   };
 
-  // the suspicious windows `rem` of the block at bbase (stream words v2 : v1 : vc) into the wave's
-  // queue: one per lane and round (ballot + mbcnt give the slots)
-  auto compact = [&](uint32_t v2, uint32_t v1, uint32_t vc, int64_t bbase, uint32_t rem) __attribute__((always_inline)) {
-    if (a.debug & 4) return;
+  // The few windows `rem` (bit i = window i of this lane) of the block at bbase (stream words
+  // v2 : v1 : vc) that the consume stage could not dismiss become suspect records {key, other fields,
+  // position | field pair << 40} for pm_pair_verify, which works out rank and slot again with every
+  // lane busy.  They are collected in a queue of this wave in LDS and leave in batches of >= 64: any
+  // global-memory instruction on this path makes the wave wait for ALL its slot loads in flight (stores
+  // and loads share the in-order vmcnt counter, so the code behind the branch has to assume the worst)
+  // -- with the L1 fill path saturated that is a microsecond and more per suspect: 5 ms per 3 Gbp.
+  auto flush = [&]() __attribute__((always_inline)) {
+    if (qn == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.susp_count, (unsigned long long)qn);   // one atomic per batch (same-address atomics serialise at ~2.5 ns each)
+    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+    for (int e = lane; e < qn; e += 64) {
+      const u32x4 q = *lds128(QB + 16 * (uint32_t)e);
+      const uint64_t pw = (uint64_t)(ws + q.z) | ((uint64_t)combo << 40);
+      if (base + (unsigned long long)e < a.susp_cap) a.susp[base + (unsigned long long)e] = make_uint4(q.x, q.y, (uint32_t)pw, (uint32_t)(pw >> 32));
+    }
+    qn = 0;
+  };
+  auto emit = [&](uint32_t v2, uint32_t v1, uint32_t vc, int64_t bbase, uint32_t rem) __attribute__((always_inline)) {
     const uint32_t prel0 = (uint32_t)(bbase - ws) + 16 * (uint32_t)lane;
     for (;;) {
       const unsigned long long bal = __ballot(rem != 0);
       if (bal == 0) break;
-      const int s = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-      if (rem != 0 && s < PAIR_QREGION) {                          // lanes the region has no room for keep their window for the next round
+      if (rem != 0) {
         const int i = __ffs(rem) - 1;
         rem &= rem - 1;
         const uint32_t sft = 2 * (uint32_t)i + 26;                   // 26 .. 56: first window bit in v2 : v1 : vc
         const uint32_t x0 = __builtin_amdgcn_alignbit(v1, v2, sft), x1 = __builtin_amdgcn_alignbit(vc, v1, sft), x2 = vc >> (sft & 31u);
-        const uint32_t wlo = sft < 32 ? x0 : x1, whi = (sft < 32 ? x1 : x2) & 0xffu;
-        u32x2 e;
-        e.x = wlo; e.y = whi | ((prel0 + (uint32_t)i) << 8);
-        *lds64(QB + qr * (PAIR_QREGION * 8) + 8 * s) = e;
+        const uint64_t W = ((uint64_t)((sft < 32 ? x1 : x2) & 0xffu) << 32) | (sft < 32 ? x0 : x1);
+        const int s_ = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        u32x4 q;
+        q.x = field_of(W, A) | (field_of(W, B) << 10); q.y = field_of(W, C) | (field_of(W, D) << 10); q.z = prel0 + (uint32_t)i; q.w = 0;
+        if (!(a.debug & 2)) *lds128(QB + 16 * (uint32_t)s_) = q;
       }
       qn += __popcll(bal);
-      if (qn >= PAIR_QREGION) { qn = PAIR_QREGION; drain(); }
+      if (qn >= 64) { if (a.debug & 4) qn = 0; else flush(); }       // (a round adds at most 64: the queue holds 128)
     }
   };
 
-  // test stage of half a block: keys, bitmap bits (into acc, funnelled from the top), and the direct
-  // table's loads into E
-  auto test = [&](auto HALF, uint32_t prev2, uint32_t prev1, uint32_t cur, int32_t (&E)[8], uint32_t &acc) __attribute__((always_inline)) {
+  // test stage of half a block: keys, bitmap bits (into acc, funnelled from the top), and the slot
+  // loads into E
+  auto test = [&](auto HALF, uint32_t prev2, uint32_t prev1, uint32_t cur, u32x2 (&E)[8], uint32_t &acc) __attribute__((always_inline)) {
     constexpr int H = decltype(HALF)::value;
     uint32_t ks[8], wd[8];
 #pragma unroll
@@ -447,34 +421,32 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     __builtin_amdgcn_sched_barrier(0);                              // issue the eight reads before the first verdict waits
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t v = wd[j] >> ((ks[j] >> 17) & 31u);            // bits 15..19 of the key pick the bit
+      const uint32_t bit = (ks[j] >> 17) & 31u;                     // bits 15..19 of the key pick the bit
+      const uint32_t v = wd[j] >> bit;
       acc = __builtin_amdgcn_alignbit(v, acc, 1);
-      // table index = key for a survivor, 0 otherwise (byte offset 2 * key from the key at bits 2..21)
-      const uint32_t off = __builtin_amdgcn_bitop3_b32(ks[j] >> 1, (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1), moff, 0x80);   // three-way AND
-      E[j] = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(direct) + off);   // plain load: nontemporal ran 3x, sc1 1.7x slower
+      // the key's slot: row * stride + rank inside the row (keys beyond the row's slots: its last slot, the overflow
+      // marker); a window whose key is absent gets row 0 -- any slot of it will do, its verdict is masked by `acc`
+      const uint32_t lr = min((uint32_t)__popc(__builtin_amdgcn_ubfe(wd[j], 0, bit)), kmax);
+      const uint32_t rowh = ks[j] & 0x1fffcu & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1);
+      const uint32_t off = rowh * rowmul + (lr << 3);
+      E[j] = *reinterpret_cast<const u32x2 *>(slots + off);           // plain load: nontemporal ran 3x, sc1 1.7x slower
     }
   };
 
-  // Software pipeline, one block deep: the entries a half block's test stage loads are consumed
-  // after the same half of the NEXT block has been tested -- about 300 instructions of this wave (and
-  // as many of each of the three other waves of its SIMD) later; with half a block of distance the
-  // table loads (the L1 fill path runs saturated: one 128-byte line per lookup) were still waited for.
-  // Block parity is compile time (two entry buffers per half, two sets of block state).
-  int32_t E[2][2][8];                                               // [block parity][half][window]
-  uint32_t sv2[2] = {0, 0}, sv1[2] = {0, 0}, svc[2] = {0, 0}, srem[2] = {0, 0};   // per parity: stream words, bitmap survivors
-  int64_t sbb[2] = {ws, ws};
+  // Software pipeline, half a block deep: the slots a half block's test stage loads are consumed after
+  // the OTHER half's test stage has issued its loads and the half before has been consumed -- about
+  // 270 instructions of this wave (and as many of each of the three other waves of its SIMD) later:
+  // 16 slot loads in flight per wave, 2800 lines per CU, against an L1 fill path that moves one line per
+  // ~2 cycles.  (A whole block of distance needs 32 more registers for the slots and spilled.)
+  u32x2 E0[8], E1[8];                                               // slots of the current block's first half / of the last tested second half
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) E[q][hh][i] = 0;
+  for (int i = 0; i < 8; ++i) { E0[i].x = 0; E0[i].y = 0; E1[i].x = 0; E1[i].y = 0; }
   const std::integral_constant<int, 0> H0;
   const std::integral_constant<int, 1> H1;
-  int64_t bb = ws;
+  uint32_t pv2 = 0, pv1 = 0, pvc = 0, prem = 0, pslow0 = 0;          // previous block: stream words, bitmap survivors, verdicts of its first half
+  int64_t pbb = ws, bb = ws;
   bool have_prev = false;                                           // wave-uniform
-  auto block = [&](auto PAR) __attribute__((always_inline)) {
-    constexpr int P = decltype(PAR)::value, O = P ^ 1;
+  while (bb < own_hi) {
     const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
     if (bb + 4096 < own_hi) q3 = load_packed(a.packed, a.npacked, bb + 4096 + 16 * lane);
@@ -490,38 +462,23 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
       own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
     }
-    uint32_t acc = 0, slow = 0;
-    test(H0, prev2, prev1, cur, E[P][0], acc);
-    if (have_prev) slow = consume(H0, sv2[O], sv1[O], svc[O], E[O][0]);
-    test(H1, prev2, prev1, cur, E[P][1], acc);
-    if (have_prev) {
-      slow |= consume(H1, sv2[O], sv1[O], svc[O], E[O][1]) << 8;
-      compact(sv2[O], sv1[O], svc[O], sbb[O], slow & srem[O]);
+    uint32_t acc = 0;
+    test(H0, prev2, prev1, cur, E0, acc);
+    if (have_prev) {                                                // the previous block is complete now
+      const uint32_t slow = (pslow0 | (consume(H1, pv2, pv1, pvc, E1) << 8)) & prem;
+      if (!(a.debug & 1) && __ballot(slow != 0)) emit(pv2, pv1, pvc, pbb, slow);
     }
-    sv2[P] = prev2; sv1[P] = prev1; svc[P] = cur; srem[P] = (acc >> 16) & own; sbb[P] = bb;
+    test(H1, prev2, prev1, cur, E1, acc);
+    pslow0 = consume(H0, prev2, prev1, cur, E0);
+    pv2 = prev2; pv1 = prev1; pvc = cur; prem = (acc >> 16) & own; pbb = bb;
     have_prev = true;
     bb += 1024;
-  };
-  const std::integral_constant<int, 0> P0;
-  const std::integral_constant<int, 1> P1;
-  bool last_odd = false;                                            // parity of the last block tested
-  while (bb < own_hi) {
-    block(P0); last_odd = false;
-    if (bb >= own_hi) break;
-    block(P1); last_odd = true;
   }
-  if (have_prev) {                                                  // the last block's entries
-    if (last_odd) {
-      const uint32_t slow = consume(H0, sv2[1], sv1[1], svc[1], E[1][0]) | (consume(H1, sv2[1], sv1[1], svc[1], E[1][1]) << 8);
-      compact(sv2[1], sv1[1], svc[1], sbb[1], slow & srem[1]);
-    } else {
-      const uint32_t slow = consume(H0, sv2[0], sv1[0], svc[0], E[0][0]) | (consume(H1, sv2[0], sv1[0], svc[0], E[0][1]) << 8);
-      compact(sv2[0], sv1[0], svc[0], sbb[0], slow & srem[0]);
-    }
+  if (have_prev) {                                                  // the last block's second half
+    const uint32_t slow = (pslow0 | (consume(H1, pv2, pv1, pvc, E1) << 8)) & prem;
+    if (!(a.debug & 1) && __ballot(slow != 0)) emit(pv2, pv1, pvc, pbb, slow);
   }
-  if (qn) drain();
-  finish();
-  if (lane < sb_left && sb_next + lane < a.susp_cap) a.susp[sb_next + lane] = make_uint4(PAIR_SUSPECT_HOLE, 0, 0, 0);
+  flush();
 }
 
 __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_scan(PairArgs a) {
@@ -542,9 +499,9 @@ __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_scan(PairArgs a) {
   }
   if (cj >= a.nchunks || combo >= a.ncombos) return;
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.image + (size_t)combo * PAIR_IMAGE_WORDS);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.image + (size_t)combo * PAIR_BITMAP_WORDS);
     u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
-    for (int i = threadIdx.x; i < PAIR_IMAGE_WORDS / 4; i += PAIR_THREADS) dst[i] = src[i];
+    for (int i = threadIdx.x; i < PAIR_BITMAP_WORDS / 4; i += PAIR_THREADS) dst[i] = src[i];
   }
   __syncthreads();
   const int fa = a.fa[combo], fb = a.fb[combo];
@@ -564,7 +521,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_scan(PairArgs a) {
 // ---- host side: tables, launch -------------------------------------------------------------------
 
 std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids, const Alphabet &alpha, int k,
-                       int eos_code, PairTables *out) {
+                       int eos_code, PairTables *out, int stride_knob) {
   PairTables &t = *out;
   t = PairTables();
   if (k < 1 || k > 2) return "the pair plan is built for k = 1 and k = 2";
@@ -610,15 +567,21 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
   if (k == 1) { t.ncombos = 2; t.fa[0] = 0; t.fb[0] = 1; t.fa[1] = 2; t.fb[1] = 3; }
   else { t.ncombos = 0; for (int x = 0; x < 4; ++x) for (int y = x + 1; y < 4; ++y) { t.fa[t.ncombos] = x; t.fb[t.ncombos] = y; ++t.ncombos; } }
   const int C = t.ncombos;
-  t.image.assign((size_t)C * PAIR_IMAGE_WORDS, 0);
+  // Slots per row of the slot table: rows (32 keys each) hold a Poisson number of the keys that occur, 5.5 on
+  // average at 200k patterns; the last slot of a row is its overflow marker.  12 slots = 96 bytes per row keep
+  // a field pair's table at 3 MiB -- inside an XCD's 4 MiB of L2 -- with 0.3 % of the keys beyond their row.
+  t.stride = stride_knob >= 2 && stride_knob <= 33 ? stride_knob : 12;
+  const size_t ST = (size_t)t.stride, KMAX = ST - 1;
+  t.image.assign((size_t)C * PAIR_BITMAP_WORDS, 0);
   t.order.assign((size_t)C * np, 0);
-  t.direct.assign((size_t)C << 20, 0);
-  std::vector<std::vector<uint32_t>> ent(C), fp(C);
+  t.slots.assign((size_t)C * PAIR_BITMAP_WORDS * ST, 0);
+  t.row_base.assign((size_t)C * (PAIR_BITMAP_WORDS + 1), 0);
+  std::vector<std::vector<uint32_t>> fp(C);
   auto build_combo = [&](int ci) {
     const int fa = t.fa[ci], fb = t.fb[ci];
     int fc, fd;
     other_fields(fa, fb, &fc, &fd);
-    // sort key = position of the key's bit in the bitmap (word major), then pattern index
+    // sort key = position of the key's bit in the bitmap (row major), then pattern index
     std::vector<uint64_t> srt(np);
     for (size_t j = 0; j < np; ++j) {
       const uint32_t key = field_of(t.pat40[j], fa) | (field_of(t.pat40[j], fb) << 10);
@@ -626,16 +589,21 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
       srt[j] = ((uint64_t)bitpos << 32) | (uint64_t)j;
     }
     std::sort(srt.begin(), srt.end());
-    uint32_t *img = &t.image[(size_t)ci * PAIR_IMAGE_WORDS];
+    uint32_t *img = &t.image[(size_t)ci * PAIR_BITMAP_WORDS];
     uint32_t *ord = &t.order[(size_t)ci * np];
-    int16_t *dir = &t.direct[(size_t)ci << 20];
-    std::vector<uint32_t> &e = ent[ci], &f = fp[ci];
-    e.reserve(2 * np); f.reserve(np + 1);
+    uint64_t *slot = &t.slots[(size_t)ci * PAIR_BITMAP_WORDS * ST];
+    uint32_t *rb = &t.row_base[(size_t)ci * (PAIR_BITMAP_WORDS + 1)];
+    std::vector<uint32_t> &f = fp[ci];
+    f.reserve(np + 1);
+    for (size_t r = 0; r < (size_t)PAIR_BITMAP_WORDS; ++r) slot[r * ST + KMAX] = slot_pack(0, 0, 0, true);   // overflow markers
+    uint32_t cur_row = 0, in_row = 0;
     for (size_t j = 0; j < np;) {
       const uint32_t bitpos = (uint32_t)(srt[j] >> 32);
       size_t j2 = j;
       while (j2 < np && (uint32_t)(srt[j2] >> 32) == bitpos) ++j2;
-      img[bitpos >> 5] |= 1u << (bitpos & 31u);
+      const uint32_t row = bitpos >> 5;
+      while (cur_row < row) { rb[++cur_row] = (uint32_t)f.size(); in_row = 0; }
+      img[row] |= 1u << (bitpos & 31u);
       f.push_back((uint32_t)j);
       uint32_t o[3] = {0, 0, 0};
       for (size_t q = j; q < j2; ++q) {
@@ -643,29 +611,13 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
         ord[q] = pi;
         if (q - j < 3) o[q - j] = field_of(t.pat40[pi], fc) | (field_of(t.pat40[pi], fd) << 10);
       }
-      const uint64_t slot = slot_pack(o[0], o[1], o[2], (uint32_t)std::min<size_t>(j2 - j, 4));
-      const uint32_t ex = (uint32_t)slot;
-      e.push_back(ex); e.push_back((uint32_t)(slot >> 32));
-      // direct-mapped by key: six bases of the first pattern's other fields; top four bits = -(k + 1), or -8 when
-      // further patterns share the key (what the consume stage adds to its mismatch count: negative = suspicious)
-      const uint32_t key = (bitpos >> 5) | ((bitpos & 31u) << 15);
-      dir[key] = (int16_t)(uint16_t)((ex & 0xfffu) | (j2 - j > 1 ? 0x8000u : ((uint32_t)(16 - (k + 1)) << 12)));
+      for (size_t q = j2 - j; q < 3; ++q) o[q] = o[0];               // free fields repeat the first pattern
+      if (in_row < KMAX) slot[(size_t)row * ST + in_row] = slot_pack(o[0], o[1], o[2], j2 - j > 3);
+      ++in_row;
       j = j2;
     }
+    while (cur_row < (uint32_t)PAIR_BITMAP_WORDS) rb[++cur_row] = (uint32_t)f.size();
     f.push_back((uint32_t)np);
-    // rank directory: set bits before every 2048-bit superblock (u32) and, inside it, before every 256-bit block (u16)
-    uint32_t *sup = img + PAIR_BITMAP_WORDS;
-    uint16_t *rel = reinterpret_cast<uint16_t *>(img + PAIR_BITMAP_WORDS + PAIR_SUPER);
-    uint32_t run = 0;
-    for (int sb = 0; sb < PAIR_SUPER; ++sb) {
-      sup[sb] = run;
-      uint32_t in = 0;
-      for (int b = 0; b < 8; ++b) {
-        rel[sb * 8 + b] = (uint16_t)in;
-        for (int w = 0; w < 8; ++w) in += (uint32_t)__builtin_popcount(img[sb * 64 + b * 8 + w]);
-      }
-      run += in;
-    }
   };
   if (np * (size_t)C < 20000) for (int ci = 0; ci < C; ++ci) build_combo(ci);
   else {
@@ -674,8 +626,6 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
     for (std::thread &x : th) x.join();
   }
   for (int ci = 0; ci < C; ++ci) {
-    t.entries_off[ci] = t.entries.size() / 2;
-    t.entries.insert(t.entries.end(), ent[ci].begin(), ent[ci].end());
     t.first_off[ci] = t.first_pat.size();
     t.first_pat.insert(t.first_pat.end(), fp[ci].begin(), fp[ci].end());
   }
@@ -684,8 +634,8 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
 
 hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
   pair_free(d);
-  d->k = t.k; d->maxlen = t.maxlen; d->ncombos = t.ncombos; d->eos_code = t.eos_code; d->ascii = t.ascii; d->np = t.pat40.size();
-  for (int c = 0; c < PAIR_MAX_COMBOS; ++c) { d->fa[c] = t.fa[c]; d->fb[c] = t.fb[c]; d->entries_off[c] = t.entries_off[c]; d->first_off[c] = t.first_off[c]; }
+  d->k = t.k; d->maxlen = t.maxlen; d->ncombos = t.ncombos; d->eos_code = t.eos_code; d->ascii = t.ascii; d->np = t.pat40.size(); d->stride = t.stride;
+  for (int c = 0; c < PAIR_MAX_COMBOS; ++c) { d->fa[c] = t.fa[c]; d->fb[c] = t.fb[c]; d->first_off[c] = t.first_off[c]; }
   auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
     if (e != hipSuccess) return e;
@@ -693,8 +643,8 @@ hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
   };
   hipError_t e;
   if ((e = up(t.image.data(), t.image.size() * 4, (void **)&d->image)) != hipSuccess) return e;
-  if ((e = up(t.entries.data(), t.entries.size() * 4, (void **)&d->entries)) != hipSuccess) return e;
-  if ((e = up(t.direct.data(), t.direct.size() * 2, (void **)&d->direct)) != hipSuccess) return e;
+  if ((e = up(t.slots.data(), t.slots.size() * 8, (void **)&d->slots)) != hipSuccess) return e;
+  if ((e = up(t.row_base.data(), t.row_base.size() * 4, (void **)&d->row_base)) != hipSuccess) return e;
   if ((e = up(t.first_pat.data(), t.first_pat.size() * 4, (void **)&d->first_pat)) != hipSuccess) return e;
   if ((e = up(t.order.data(), t.order.size() * 4, (void **)&d->order)) != hipSuccess) return e;
   if ((e = up(t.pat40.data(), t.pat40.size() * 8, (void **)&d->pat40)) != hipSuccess) return e;
@@ -711,7 +661,7 @@ hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
 }
 
 void pair_free(PairDevice *d) {
-  void *ptrs[] = {d->image, d->entries, d->direct, d->first_pat, d->order, d->pat_id, d->pat40, d->pat_len, d->pat_codes, d->pat_zone};
+  void *ptrs[] = {d->image, d->slots, d->row_base, d->first_pat, d->order, d->pat_id, d->pat40, d->pat_len, d->pat_codes, d->pat_zone};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = PairDevice();
 }
@@ -719,12 +669,9 @@ void pair_free(PairDevice *d) {
 ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end) {
   ScanGeometry g;
   int64_t chunk = 1 << 19;                                         // 512 Ki positions per workgroup
-  // large ranges: 2 Mi positions per workgroup amortise staging the 146 KiB LDS image
+  // large ranges: 2 Mi positions per workgroup amortise staging the 128 KiB LDS image
   if ((end - begin) / ((int64_t)1 << 21) * d.ncombos >= 256 * 8) chunk = (int64_t)1 << 21;
-  if (const char *env = getenv("PM_SEED_CHUNK")) {                 // test knob (shared with the seed kernels)
-    const int64_t v = atoll(env);
-    if (v >= 1024 * WAVES) chunk = v / (1024 * WAVES) * (1024 * WAVES);
-  }
+  if (d.knobs.seed_chunk >= 1024 * WAVES) chunk = d.knobs.seed_chunk / (1024 * WAVES) * (1024 * WAVES);   // test knob (shared with the seed kernels)
   g.seg_len = chunk;
   const int64_t c_lo = begin / chunk, c_hi = end > begin ? (end - 1) / chunk : c_lo - 1;
   g.nseg = (int)(c_hi - c_lo + 1);
@@ -747,14 +694,12 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   a.packed = d_packed; a.npacked = (n + 15) / 16;
   a.chunk_len = g.seg_len; a.chunk0 = begin / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;
-  if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
+  if (d.knobs.seed_group > 0) a.group = d.knobs.seed_group;
   a.k = d.k; a.eos_code = d.eos_code;
-  if (const char *env = getenv("PM_SEED_DEBUG")) a.debug = atoi(env);
-  for (int c = 0; c < PAIR_MAX_COMBOS; ++c) {
-    a.fa[c] = d.fa[c]; a.fb[c] = d.fb[c];
-    a.entries_off[c] = (uint32_t)d.entries_off[c]; a.first_off[c] = (uint32_t)d.first_off[c];
-  }
-  a.image = d.image; a.direct = d.direct; a.entries = reinterpret_cast<const uint2 *>(d.entries); a.first_pat = d.first_pat; a.order = d.order;
+  a.debug = d.knobs.seed_debug;
+  for (int c = 0; c < PAIR_MAX_COMBOS; ++c) { a.fa[c] = d.fa[c]; a.fb[c] = d.fb[c]; a.first_off[c] = (uint32_t)d.first_off[c]; }
+  a.stride = d.stride;
+  a.image = d.image; a.slots = reinterpret_cast<const uint2 *>(d.slots); a.row_base = d.row_base; a.first_pat = d.first_pat; a.order = d.order;
   a.np = (uint32_t)d.np;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id; a.pat_codes = d.pat_codes; a.pat_zone = d.pat_zone; a.viol_level = d.viol_level;
   a.out = d_out; a.counter = d_counter; a.cap = cap;

@@ -70,12 +70,13 @@ struct SeedDevice {
   bool ascii = false;
   size_t nslots = 0;
   int idx_bits = 0, bucket_shift = 0;
+  Knobs knobs;                                    // set by the caller after seed_upload
 };
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
                        const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin = 0,
                        const std::vector<std::string> *partners = nullptr, const std::vector<uint8_t> *sides = nullptr,
-                       int halves_k = 0, bool edits = false);
+                       int halves_k = 0, bool edits = false, const Knobs &knobs = Knobs());
 hipError_t seed_upload(const SeedTables &t, SeedDevice *d, hipStream_t st);
 void seed_free(SeedDevice *d);
 ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end);

@@ -1884,7 +1884,7 @@ static void edit_cover(int k, int m, const std::vector<std::array<int, 4>> &comb
 
 std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids,
                        const Alphabet &alpha, int k, int eos_code, SeedTables *out, int force_lmin,
-                       const std::vector<std::string> *partners, const std::vector<uint8_t> *sides, int halves_k, bool edits) {
+                       const std::vector<std::string> *partners, const std::vector<uint8_t> *sides, int halves_k, bool edits, const Knobs &knobs) {
   SeedTables &t = *out;
   t = SeedTables();
   t.k = k;
@@ -1977,7 +1977,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   // buckets of 8 slots, average fill <= 3; slot = fingerprint (high bits) | pattern index (low idx_bits)
   int idx_bits = 1;
   while (((size_t)1 << idx_bits) <= np) ++idx_bits;
-  const bool edit_bloom_v1 = edits && getenv("PM_EDIT_SCAN") && !strcmp(getenv("PM_EDIT_SCAN"), "bloom");
+  const bool edit_bloom_v1 = edits && knobs.edit_bloom;
   const bool tabulated = edits && !edit_bloom_v1;  // first stage pm_edit_scan: 64-byte buckets of 16 slots (a full bucket is then a 1e-3 event)
   const size_t bslots = tabulated ? EDIT_BUCKET : 8;
   size_t nbuckets = 256;
@@ -1998,7 +1998,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   t.etable_log = 0;
   if (tabulated) {
     t.etable_log = 23;                               // 2^23 key-hash bits = 1 MiB per combo: with the 2 MiB of buckets it stays in one XCD's L2
-    if (const char *env = getenv("PM_EDIT_TABLE_LOG")) { const int v = atoi(env); if (v >= 16 && v <= 26) t.etable_log = v; }
+    if (knobs.edit_table_log >= 16 && knobs.edit_table_log <= 26) t.etable_log = knobs.edit_table_log;
     if (nslots > ((size_t)1 << 20)) return "pattern tile too large for the edit-distance plan's seed records (20-bit slot index)";
     t.etable.assign((size_t)C << (t.etable_log - 3), 0); t.eidx.assign((size_t)C * nslots, 0);
   }
@@ -2044,7 +2044,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
       const int L = (int)pats[j].s.size(), plen = t.part_len[j];
       if (t.part_side[j] ? L + plen + halves_k <= 32 : plen + halves_k <= 16) ++half_fits;
     }
-  if (partners && np > 0 && lmin >= 10 && half_fits * 10 >= np * 9 && !(getenv("PM_HALF_SCAN") && !strcmp(getenv("PM_HALF_SCAN"), "bloom"))) {
+  if (partners && np > 0 && lmin >= 10 && half_fits * 10 >= np * 9 && !knobs.half_bloom) {
     std::vector<uint64_t> srt(np);
     for (size_t j = 0; j < np; ++j) {
       const std::string &s = pats[j].s;
@@ -2241,10 +2241,7 @@ ScanGeometry seed_geometry(const SeedDevice &d, int64_t begin, int64_t end) {
   // still has dozens of workgroups per CU; the one- and four-combo plans and the edit-distance plan
   // measured no gain or a loss (sweep in DESIGN.md section 7)
   if (!d.edits && !d.halves && d.ncombos >= 8 && (end - begin) / ((int64_t)1 << 21) * d.ncombos >= 256 * 16) chunk = (int64_t)1 << 21;
-  if (const char *env = getenv("PM_SEED_CHUNK")) {                 // test knob
-    const int64_t v = atoll(env);
-    if (v >= 1024 * WAVES) chunk = v / (1024 * WAVES) * (1024 * WAVES);
-  }
+  if (d.knobs.seed_chunk >= 1024 * WAVES) chunk = d.knobs.seed_chunk / (1024 * WAVES) * (1024 * WAVES);   // test knob
   g.seg_len = chunk;
   if (d.edits) { begin = begin > d.edits ? begin - d.edits : 0; end += d.edits; }   // seeds up to k positions outside (begin, end]
   const int64_t c_lo = begin / chunk, c_hi = end > begin ? (end - 1) / chunk : c_lo - 1;
@@ -2268,10 +2265,9 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
   a.chunk_len = g.seg_len; a.chunk0 = (d.edits && begin > d.edits ? begin - d.edits : (d.edits ? 0 : begin)) / g.seg_len; a.nchunks = g.nseg; a.ncombos = d.ncombos;
   a.group = 256;                                                   // one run ~ one chunk per CU
   if (d.edits && d.edit_tabulated) a.group = 512;                   // pm_edit_scan (3 Gbp, 100k primers): 128: 86.8 ms, 256: 82.2, 512: 81.3, 1024: 81.1, 2048: 83.9
-  if (const char *env = getenv("PM_SEED_GROUP")) { const int v = atoi(env); if (v > 0) a.group = v; }
+  if (d.knobs.seed_group > 0) a.group = d.knobs.seed_group;
   a.k = d.k; a.Lw = d.Lw; a.pb = d.pb; a.r = d.r; a.ascii = d.ascii ? 1 : 0;
-  a.debug = 0;
-  if (const char *env = getenv("PM_SEED_DEBUG")) a.debug = atoi(env);
+  a.debug = d.knobs.seed_debug;
   memcpy(a.mask_lo, d.mask_lo, sizeof(a.mask_lo));
   memcpy(a.mask_hi, d.mask_hi, sizeof(a.mask_hi));
   memcpy(a.perm_sel, d.perm_sel, sizeof(a.perm_sel));

@@ -231,7 +231,6 @@ struct Hit { int64_t key; unsigned long id; unsigned char value; };
 int main(int argc, char **argv) {
   const int nranks = take_ranks_option(&argc, argv);                  // --ranks N: one process per GPU, the stream sharded by position
   Options opt = parse(argc, argv);
-  RankGroup ranks = RankGroup::launch(nranks);                      // returns in every rank process; forks before anything touches a GPU
   Phases ph; ph.on = opt.chatty;
   std::ofstream fout;
   if (!opt.out_path.empty()) fout.open(opt.out_path.c_str(), std::ios::out | std::ios::app | std::ios::ate);
@@ -275,6 +274,9 @@ int main(int argc, char **argv) {
   }
   if (patterns.empty()) return 0;
   if (patterns.size() % 2 != 0) usage("Odd number of primers!");
+  // the ranks are forked only now: the primers may come from stdin ("-"), which the rank processes would otherwise
+  // share -- one would drain it, or each would read a different slice and build different tables.  Nothing above touches a GPU.
+  RankGroup ranks = RankGroup::launch(nranks);                      // returns in every rank process
   if (opt.to_upper) for (std::string &p : patterns) uppercase(p);
   if (opt.both_strands || opt.primers_from_sts) {
     opt.both_strands = true;

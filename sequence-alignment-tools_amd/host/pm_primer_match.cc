@@ -275,7 +275,6 @@ std::string with_gaps(const std::string &src, const std::string &ops, char gap_o
 int main(int argc, char **argv) {
   const int nranks = take_ranks_option(&argc, argv);                  // --ranks N: one process per GPU, the stream sharded by position
   Options opt = parse(argc, argv);
-  RankGroup ranks = RankGroup::launch(nranks);                      // returns in every rank process; forks before anything touches a GPU
   Phases ph; ph.on = opt.chatty;
   std::ofstream fout;
   if (!opt.out_path.empty()) fout.open(opt.out_path.c_str(), std::ios::out | std::ios::app | std::ios::ate);
@@ -319,6 +318,9 @@ int main(int argc, char **argv) {
   }
   if (patterns.empty()) return 0;
   ph.mark("Read primers");
+  // the ranks are forked only now: the primers may come from stdin ("-"), which the rank processes would otherwise
+  // share -- one would drain it, or each would read a different slice and build different tables.  Nothing above touches a GPU.
+  RankGroup ranks = RankGroup::launch(nranks);                      // returns in every rank process
   if (opt.to_upper) for (std::string &p : patterns) uppercase(p);
 
   const unsigned long n = patterns.size();

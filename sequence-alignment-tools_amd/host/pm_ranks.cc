@@ -2,6 +2,7 @@
 #include "pm_ranks.h"
 
 #include <dirent.h>
+#include <signal.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -120,12 +121,24 @@ RankGroup RankGroup::launch(int world) {
     kids[r] = pid;
   }
   for (int q = 1; q < world; ++q) { close(up_r[q]); close(up_w[q]); close(down_r[q]); close(down_w[q]); }
-  int status = 0;
-  for (int r = 0; r < world; ++r) {
+  // Wait for whichever rank ends first.  A rank that fails (fatal() after the count exchange, a
+  // transport error) leaves its peers blocked in a receive that will never complete -- pipe EOF only
+  // covers the host transport -- so the first non-zero status ends the others (SIGTERM to the exact
+  // pids forked above) and becomes the launcher's status.
+  int status = 0, left = world;
+  while (left > 0) {
     int st = 0;
-    while (waitpid(kids[r], &st, 0) < 0 && errno == EINTR) {}
+    const pid_t done = waitpid(-1, &st, 0);
+    if (done < 0) { if (errno == EINTR) continue; break; }
+    int r = -1;
+    for (int q = 0; q < world; ++q) if (kids[q] == done) r = q;
+    if (r < 0) continue;
+    kids[r] = 0; --left;
     const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-    if (code && !status) status = code;
+    if (code && !status) {
+      status = code;
+      for (int q = 0; q < world; ++q) if (kids[q] > 0) kill(kids[q], SIGTERM);
+    }
   }
   fflush(stdout);
   _exit(status);

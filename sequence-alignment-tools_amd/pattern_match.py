@@ -49,7 +49,7 @@ def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
-    subprocess.check_call(["make", "-s", "-C", _CSRC])
+    subprocess.check_call(["make", "-s", "-j8", "-C", _CSRC])
     return library_path()
 
 

@@ -32,7 +32,7 @@ def free_port():
 
 def run_bench(ranks, k, indels, dump, extra=()):
     common = ["bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--db-bases", str(DB), "--primers", str(PRIMERS),
-              "--k", str(k), "--indels", str(indels), "--scaling", "strong", "--no-cpu", "--dump-hits", dump, *extra]
+              "--k", str(k), "--indels", str(indels), "--no-cpu", "--dump-hits", dump, *extra]     # default scaling: strong
     env = dict(os.environ, PM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if ranks == 1:
         cmd = [sys.executable] + common
@@ -54,6 +54,22 @@ def test_two_ranks_equal_one_rank(tmp_path, k, indels):
     assert h1.size > 0
     assert h1.size == h2.size and (h1 == h2).all(), (h1.size, h2.size)
     assert j2["config"]["final_hits"] == h2.size
+    # BASELINE.json's metric is one database "at 1/2/4/8 GPUs": the default N > 1 line reports the SAME total stream,
+    # split over the ranks, and says so; it also carries the exchange's cost and every rank's kernel time
+    assert j1["scaling"] == j2["scaling"] == "strong"
+    assert j1["config"]["db_bases_total"] == j2["config"]["db_bases_total"] == DB
+    assert j2["config"]["db_bases_per_gpu"] == DB // 2 and j1["config"]["db_bases_per_gpu"] == DB
+    assert "0.05 Gbp stream in total = 0.025 Gbp per GPU x 2 GPU(s)" in j2["config"]["workload"], j2["config"]["workload"]
+    assert j2["exchange_ms"] is not None and j2["exchange_ms"] >= 0 and len(j2["kernel_ms_per_rank"]) == 2
+    assert all(x > 0 for x in j2["kernel_ms_per_rank"])
+
+
+def test_default_workload_is_the_three_gbp_database_in_total():
+    """no flags but --gpus: the line would name 3 Gbp in total (argument defaults, read without running)"""
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert re.search(r'"--db-bases", type=int, default=3_000_000_000', src)
+    assert re.search(r'"--scaling", choices=\["weak", "strong"\], default="strong"', src)
 
 
 @pytest.mark.parametrize("k,indels", [(2, 0), (0, 0)])

@@ -170,52 +170,107 @@ def test_config_size_one_gbp_100k_primers(k):
     bp.close()
 
 
-def test_one_million_primers_eight_tiles():
-    """BASELINE config 4's pattern set: 1M 20-mers, both strands = 2M patterns = 8 pattern tiles of
-    the seed family, -K 2, 256 Mbp: planted sites of primers from every tile are reported."""
-    n, L, P = 1 << 28, 20, 1_000_000
-    dev = make_db(n, 31)
-    rng = np.random.default_rng(31)
-    host = dev[: 1 << 24].cpu().numpy()
-    plant = [x for d in range(3) for x in planted(host, rng, 240, L, d)]
+def all_hits(pm, n, capacity):
+    """every final hit of one pass over the whole stream, the way bench.py's step gets them: device
+    stage, then the clustering / verify stage on the GPU (pm_finalize_device), as a numpy array"""
+    pm.set_capacity(capacity)
+    cnt = pm.scan_candidates(0, n, to_host=False)
+    ptr, cnt2 = pm.candidates_device()
+    assert cnt == cnt2
+    return pm.finalize_device(n, last=True, sort=False, d_cands=ptr, n=cnt)
+
+
+def test_config4_one_million_primers_three_gbp():
+    """BASELINE config 4 on one GPU: 1M 20-mers, both strands = 2M patterns = 8 pattern tiles of the pair
+    plan, -K 2, against 3 Gbp.  Sites planted with 0 / 1 / 2 substitutions for primers of EVERY tile --
+    forward primers (tiles 0..3) and primers whose reverse complement is the site (tiles 4..7) -- at the
+    start of the stream, beyond 2^31 and at its far end must all be reported with at most their planted
+    distance (filter_bitvec.cc:88-177: one hit per chain, so the end may sit up to 2k+1 away); on two
+    4 Mbp slices (one beyond 2^31) the records equal the bit-parallel family's, the literal
+    shift_and_inexact automaton (shift_and_inexact.cc:249-352)."""
+    n, L, P, k = 3_000_000_000, 20, 1_000_000, 2
+    dev = make_db(n, 71)
+    rng = np.random.default_rng(71)
+    regions = [0, (1 << 31) + (1 << 27), n - (1 << 22)]
+    plant = []                                                     # (primer, end, d, tile-side: 0 forward, 1 reverse complement)
+    for r in regions:
+        w = dev[r:r + (1 << 22)].cpu().numpy()
+        for side in (0, 1):
+            for d in range(3):
+                for (p, e, dd) in planted(w, rng, 40, L, d):
+                    plant.append((sat_amd.reverse_comp(p) if side else p, e + r, dd, side))
+    assert max(e for _, e, _, _ in plant) > (1 << 31)
     rnd = random_primers(rng, P - len(plant), L)
-    # spread the planted primers over the whole id range, i.e. over all tiles
-    step = P // len(plant)
+    step = P // len(plant)                                           # spread over the whole id range: every forward tile, every reverse tile
     pats, where = list(rnd), {}
-    for j, (p, e, d) in enumerate(plant):
+    for j, (p, e, d, side) in enumerate(plant):
         pats.insert(j * step, p)
     for j in range(len(plant)):
         where[j * step] = plant[j]
     allp = pats + [sat_amd.reverse_comp(p) for p in pats]
-    pm = engine(allp, 2, sat_amd.KERNEL_AUTO, dev)
-    assert pm.selected()[1] == sat_amd.KERNEL_SEED and "tiles=8" in pm.describe(), pm.describe()
-    pm.set_capacity(1 << 24)
-    hits = pm.find_all(chunk=1 << 30)
+    pm = engine(allp, k, sat_amd.KERNEL_AUTO, dev)
+    assert pm.selected() == (sat_amd.SEM_FILTER_BITVEC, sat_amd.KERNEL_SEED)
+    hits = all_hits(pm, n, 1 << 25)
+    assert "pm_pair_scan" in pm.describe() and "tiles=8" in pm.describe(), pm.describe()
     key, kk = hit_index(hits)
-    for idx, (_, end, d) in where.items():
-        assert found(key, kk, idx + 1, end, 5, d), ("planted primer not found", idx, end, d)
+    tiles_seen = set()
+    for idx, (_, end, d, side) in where.items():
+        pid = idx + 1 + (P if side else 0)
+        assert found(key, kk, pid, end, 2 * k + 1, d), ("planted primer not found", idx, end, d, side)
+        tiles_seen.add((pid - 1) // 250_000)
+    assert tiles_seen == set(range(8)), tiles_seen
+    # expected number of spurious hits: n * 2P * (1 + 60 + 1710) / 4^20 = 9.7e6 (SURVEY 8d); clustering removes few
+    assert 8_000_000 < hits.size < 12_000_000, hits.size
+    bp = engine(allp, k, sat_amd.KERNEL_BITPAR, dev)
+    for lo in (1 << 20, (1 << 31) + (1 << 27)):
+        a = np.sort(pm.scan_candidates(lo, lo + (1 << 22)), order=["end", "pid", "k"])
+        b = np.sort(bp.scan_candidates(lo, lo + (1 << 22)), order=["end", "pid", "k"])
+        assert a.size > 1000 and a.size == b.size and (a["end"] == b["end"]).all() and (a["pid"] == b["pid"]).all() and (a["k"] == b["k"]).all(), (lo, a.size, b.size)
     pm.close()
+    bp.close()
 
 
-def test_edit_distance_plants_at_scale():
-    """-k 2 (edits) on 256 Mbp x 50k primers: primers that are database sites with 0, 1 or 2 random
-    edits (substitutions, insertions, deletions) are reported at their site with at most that many
-    edits (filter_bitvec.cc:88-177 reports one hit per chain of candidates, the end may move by the
-    edits)."""
-    n, L, P, k = 1 << 28, 22, 50_000, 2
-    dev = make_db(n, 41)
-    rng = np.random.default_rng(41)
-    host = dev[: 1 << 24].cpu().numpy()
-    plant = [x for d in range(3) for x in plant_edits(host, rng, 300, L, d)]
+def test_edit_distance_three_gbp_100k_primers():
+    """-k 2 (edits; filter_bitvec over the k-error automaton's candidates, filter_bitvec.cc:88-177,
+    shift_and_inexact.cc:249-352) at BASELINE size: 100k primers, both strands, 3 Gbp.  Primers that are
+    database sites with 0, 1 or 2 random edits (substitution, insertion, deletion) are reported at their
+    site with at most that many edits: sites at the very start of the stream, across an edge of the
+    512 Ki-position chunks of pm_edit_scan, beyond 2^31 and at the far end; on a 2 Mbp slice beyond 2^31
+    the deduplicated candidates equal the bit-parallel family's."""
+    n, L, P, k = 3_000_000_000, 22, 100_000, 2
+    dev = make_db(n, 81)
+    rng = np.random.default_rng(81)
+    plant = []
+    for r in (0, (1 << 31) + (1 << 26), n - (1 << 22)):
+        w = dev[r:r + (1 << 22)].cpu().numpy()
+        plant += [(p, a + r, sl, d) for d in range(3) for (p, a, sl, d) in plant_edits(w, rng, 100, L, d)]
+    edge = (1 << 19) * 3001                                        # a chunk edge of the edit-distance plan
+    w = dev[edge - 64:edge + 64].cpu().numpy()
+    for off in (30, 40, 44, 50, 56, 62):                           # sites that straddle or touch the edge
+        site = w[off:off + L]
+        if (site > 3).any():
+            continue
+        s_ = LUT[site].tobytes().decode()
+        plant.append((s_, edge - 64 + off, L, 0))
+        plant.append((s_[:7] + s_[8:], edge - 64 + off, L, 1))     # one deleted character
+        plant.append((s_[:12] + "ACGT"[(("ACGT".index(s_[12])) + 1) % 4] + s_[13:], edge - 64 + off, L, 1))
     pats = [p for p, _, _, _ in plant] + random_primers(rng, P - len(plant), L)
     allp = pats + [sat_amd.reverse_comp(p) for p in pats]
     pm = engine(allp, k, sat_amd.KERNEL_AUTO, dev, indels=True)
     assert pm.selected() == (sat_amd.SEM_FILTER_BITVEC, sat_amd.KERNEL_SEED)
-    hits = pm.find_all(chunk=1 << 30)
+    hits = all_hits(pm, n, 1 << 28)
+    assert "pm_edit_scan" in pm.describe() and "chunk=524288" in pm.describe(), pm.describe()
     key, kk = hit_index(hits)
     for i, (_, a, sl, d) in enumerate(plant):
         assert found(key, kk, i + 1, a + sl, 2 * k + 1 + d, d), ("planted primer not found", i, a, d)
+    assert hits.size > 2_000_000, hits.size
+    bp = engine(allp, k, sat_amd.KERNEL_BITPAR, dev, indels=True)
+    lo = (1 << 31) + (1 << 26)
+    a = np.sort(pm.scan_candidates(lo, lo + (1 << 21)), order=["end", "pid", "k"])
+    b = np.sort(bp.scan_candidates(lo, lo + (1 << 21)), order=["end", "pid", "k"])
+    assert a.size > 1000 and a.size == b.size and (a["end"] == b["end"]).all() and (a["pid"] == b["pid"]).all() and (a["k"] == b["k"]).all(), (a.size, b.size)
     pm.close()
+    bp.close()
 
 
 @pytest.mark.parametrize("L", [20, 23])

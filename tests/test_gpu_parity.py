@@ -180,6 +180,36 @@ def test_halves_seed_overflow_is_recovered():
     assert want == [tuple(h) for h in c["engine"]["auto_k1"]["hits"]]
 
 
+def test_internal_suspect_buffer_overflow_rescans_inside_the_library():
+    """The pair plan's suspect list (between pm_pair_scan and pm_pair_verify) is sized for random streams; on
+    3 x 1.4 Mbp of A against A^20 and its neighbours every window is a suspect of every field pair: the
+    buffer overflows, the library enlarges it and scans the range again by itself -- the caller's record
+    buffer (large enough all along) is neither blamed nor reallocated, pm_scan_wait returns PM_OK -- and
+    every window comes back with its distance (shift_and_inexact.cc:249-352, substitutions only)."""
+    table = b"ACGT\n"
+    lens = [1_400_000, 1_400_000, 1_400_017]
+    codes = synth.normalize(("\n" + "".join("A" * n + "\n" for n in lens)).encode(), table)
+    pats = ["A" * 20, "A" * 19 + "C", "A" * 7 + "G" + "A" * 6 + "T" + "A" * 5, "C" + "A" * 19, "ACGT" * 5]
+    pm = sat_amd.PatternMatch(k=2, indels=False, semantics=sat_amd.SEM_SHIFT_AND_INEXACT, kernel=sat_amd.KERNEL_SEED)
+    for i, p in enumerate(pats):
+        pm.add_pattern(p, i + 1)
+    pm.init(codes, table)
+    assert "pm_pair_scan" in pm.describe()
+    pm.set_capacity(1 << 25)
+    pm.scan_async(0, codes.size)
+    n = pm.scan_wait()                                              # no PmError: the rescan is the library's business
+    per_pattern = sum(x - 19 for x in lens)
+    assert 4 * per_pattern <= n <= 4 * per_pattern + 64          # + the automaton's few stream-start records (shift_and_inexact.cc:162-164)
+    ptr, cnt = pm.candidates_device()
+    rec = pm.copy_records(ptr, cnt)
+    rec = rec[rec["end"] > 24]                                      # past the stream start (ends 21..24 of the first entry dropped)
+    for pid, d in ((1, 0), (2, 1), (3, 2), (4, 1)):
+        m = rec["pid"] == pid
+        assert m.sum() == per_pattern - 4 and (rec["k"][m] == d).all(), (pid, int(m.sum()))
+    assert not (rec["pid"] == 5).any()
+    pm.close()
+
+
 def test_device_finalize_equals_host_finalize():
     """pm_finalize_device (hipCUB sort + segmented pass on the GPU) == the host stage, incl. clusters
     on tandem repeats and the deferral at the end of a partial range."""

@@ -4,7 +4,16 @@ the count exchange and the record gather run in C++ (host/pm_ranks.cc; RCCL send
 include/pm_gpu.h pm_comm_* when every rank has a GPU of its own -- on this one-GPU box the ranks
 share the card and the records travel through the launcher's pipes), rank 0 pairs
 (pcr_match.cc:948-1259) / re-aligns and prints.  The output must equal the single-rank output and
-the goldens the real reference produced; amplicons and hits that straddle shard edges included."""
+the goldens the real reference produced; amplicons and hits that straddle shard edges included.
+
+Ordering contract (checked here byte for byte): one find_patterns call returns its hits in (end, id, k)
+order; `--ranks N` covers the whole stream in one call, the single-rank program in calls of 2^30 stream
+bytes -- on databases below that size the two print exactly the same bytes.  (Above it, a chain of
+candidates deferred across a call's edge is reported by the later call, as the reference's own
+filter_bitvec does, filter_bitvec.cc:118-121, so primer_match's line order may differ at those edges;
+pcr_match sorts its hits, pcr_match.cc:958.)  Against the goldens the comparison is a multiset of
+lines: the reference engines order hits that end at the same position differently (sortedvector.t:490-510
+sorts by position only, unstably)."""
 import json
 import os
 import subprocess
@@ -50,8 +59,10 @@ def test_pcr_match_ranks_equal_reference(fixture):
         n = os.path.getsize([os.path.join(d, x) for x in os.listdir(d) if x.endswith(".sqn")][0])
         for case, c in g["cases"].items():
             base = [PCR, "-i", fa, FLAG[c["primers"]], os.path.join(d, "primers." + c["primers"])] + c["options"]
+            one = run(base)
             for ranks in (2, 5):
                 got = run(base + ["--ranks", str(ranks)])
+                assert got == one, (fixture, case, ranks)                 # byte for byte the single-rank output
                 assert sorted(got.splitlines()) == sorted(c["stdout"].splitlines()), (fixture, case, ranks)
                 assert len(got) == len(c["stdout"])
         # the fixture's 2400 bp amplicon in the third entry spans an edge of the five-rank split
@@ -77,6 +88,8 @@ def test_primer_match_ranks_equal_reference(fixture):
                 parg = ["-" + ("P" if c["primers"] == "W" else c["primers"]), os.path.join(d, "primers." + c["primers"])]
             for extra in (["--ranks", "3"], ["--ranks=2", "-N", "16"]):
                 got = run([PM, "-i", fa] + parg + c["options"] + extra)
+                one = run([PM, "-i", fa] + parg + c["options"] + extra[-2:] * (extra[-2] == "-N"))
+                assert got == one, (fixture, case, extra)                 # byte for byte the single-rank output (same -N)
                 want = c["normalized"]
                 assert sorted(got.splitlines()) == sorted(want.splitlines()), (fixture, case, extra)
                 assert len(got) == len(want)
@@ -130,7 +143,7 @@ def test_shards_larger_than_the_guard_band():
             assert one.strip(), opts
             for ranks in (3, 4):
                 got = run(base + ["--ranks", str(ranks)])
-                assert sorted(got.splitlines()) == sorted(one.splitlines()), (opts, ranks)
+                assert got == one, (opts, ranks)
             if os.path.exists(REF_PCR) and opts != ["-K", "2"]:        # the reference's -K 2 takes minutes at this size
                 ref = run([REF_PCR, "-i", fa, "-P", pp, "-r", "-M", "1000", "-A", fmt] + opts)
                 assert sorted(ref.splitlines()) == sorted(one.splitlines()), opts
@@ -141,7 +154,40 @@ def test_shards_larger_than_the_guard_band():
             base = [PM, "-i", fa, "-P", pf, "-r", "-A", "%i %r %s %e %d %H\\n"] + opts
             one = run(base)
             for ranks in (3, 4):
-                assert sorted(run(base + ["--ranks", str(ranks)]).splitlines()) == sorted(one.splitlines()), (opts, ranks)
+                assert run(base + ["--ranks", str(ranks)]) == one, (opts, ranks)
+
+
+def test_primers_on_stdin_reach_every_rank():
+    """`-P -` / `-S -` with --ranks: the primers are read before the ranks are forked (the rank processes would
+    otherwise share one stdin: one drains it, or each builds tables from a different slice)."""
+    g = load("cli_a")
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "db.fa")
+        with open(fa, "w") as f:
+            f.write(g["fasta"])
+        run([CS, "-i", fa, "-n", "true"])
+        pf = os.path.join(d, "primers.txt")
+        with open(pf, "w") as f:
+            f.write(g["primers_txt"])
+        fmt = "%i %r %s %e %d %H\\n"
+        for opts in (["-k", "1"], ["-K", "2"]):
+            want = run([PM, "-i", fa, "-P", pf, "-r", "-A", fmt] + opts)
+            assert want.strip()
+            for ranks in (2, 3):
+                got = run([PM, "-i", fa, "-P", "-", "-r", "-A", fmt, "--ranks", str(ranks)] + opts, input=g["primers_txt"].encode())
+                assert got == want, (opts, ranks)
+    g = load("pcr_a")
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "db.fa")
+        with open(fa, "w") as f:
+            f.write(g["fasta"])
+        run([CS, "-i", fa, "-n", "true"])
+        sts = os.path.join(d, "pairs.sts")
+        with open(sts, "w") as f:
+            f.write(g["primers"]["S"])
+        want = run([PCR, "-i", fa, "-S", sts, "-k", "1"])
+        got = run([PCR, "-i", fa, "-S", "-", "-k", "1", "--ranks", "2"], input=g["primers"]["S"].encode())
+        assert want.strip() and got == want
 
 
 def test_a_failing_rank_takes_the_run_down():
