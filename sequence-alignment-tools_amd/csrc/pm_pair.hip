@@ -55,7 +55,6 @@ namespace {
 
 constexpr int WAVES = PAIR_WAVES;
 constexpr uint32_t F20 = 0xfffffu;
-constexpr uint32_t PAIR_SUSPECT_HOLE = 0xffffffffu;                  // rank field of a reserved slot that stayed unused
 constexpr uint32_t WHAT_REST = 8u, WHAT_ALL = 16u;                   // suspect: walk the key's patterns from the fourth / from the first
 // Slot of a key, 8 bytes: the other 20 window bits of up to three patterns that have the key
 // (o1 | o2 << 20 | o3 << 40; with fewer than three patterns the free fields repeat o1) and bit 63 =
@@ -227,15 +226,20 @@ __device__ __forceinline__ void pair_emit(const PairArgs &a, bool ok, const pm_h
 // A suspect: a window whose slot says "within k on the other fields" for the key's first / second /
 // third pattern (what & 1, 2, 4), that the key has more than three (WHAT_REST: walk the rest of the
 // key's run of the sorted pattern list), or whose key has no slot (WHAT_ALL: walk the whole run).
-__device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint32_t rank, uint32_t what, uint32_t wo, int64_t p) {
+__device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint32_t rank, uint32_t what, uint32_t wo, int64_t p, pm_hit *first, bool *have) {
   const uint32_t *fp = a.first_pat + a.first_off[combo];
   const uint32_t *ord = a.order + (size_t)combo * a.np;
   const uint32_t t0 = fp[rank], t1 = fp[rank + 1];
   pm_hit hh;
-  for (uint32_t j = 0; j < 3; ++j) {
-    const bool ok = ((what >> j) & 1u) && t0 + j < t1 && pair_verify(a, combo, p, ord[t0 + j], &hh);   // (free slot fields repeat the first pattern)
-    pair_emit(a, ok, hh);
-  }
+  // the suspect's first record stays in registers (the kernel writes those block by block), further ones -- a
+  // window within k of two patterns that share the key -- go out one by one
+  auto take = [&](bool ok) __attribute__((always_inline)) {
+    const bool extra = ok && *have;
+    if (ok && !*have) { *first = hh; *have = true; }
+    pair_emit(a, extra, hh);
+  };
+  for (uint32_t j = 0; j < 3; ++j)
+    take(((what >> j) & 1u) && t0 + j < t1 && pair_verify(a, combo, p, ord[t0 + j], &hh));   // (free slot fields repeat the first pattern)
   if (what & (WHAT_REST | WHAT_ALL)) {
     int c, d;
     other_fields(a.fa[combo], a.fb[combo], &c, &d);
@@ -244,39 +248,63 @@ __device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint3
       const uint2 pp = a.pat40[pi];
       const uint64_t W = ((uint64_t)pp.y << 32) | pp.x;
       const uint32_t po = field_of(W, c) | (field_of(W, d) << 10);
-      const bool ok = sym_distance(po ^ wo) <= a.k && pair_verify(a, combo, p, pi, &hh);
-      pair_emit(a, ok, hh);
+      take(sym_distance(po ^ wo) <= a.k && pair_verify(a, combo, p, pi, &hh));
     }
   }
 }
 
-// Second kernel: the scan kernel's suspects (a few per thousand positions), one per lane, grid-stride;
-// the count is read from device memory.  Here, with every lane busy, the dependent loads of the
-// verify (pattern list, pattern, raw stream bytes) cost little; inside the scan kernel they ran with
-// one or two live lanes per wave and held the wave for microseconds.
+// Second kernel: the scan kernel's suspects (a few per thousand positions), one per thread; the count is read
+// from device memory.  Here, with every lane busy, the dependent loads of the verify (bitmap row, slot, pattern
+// list, pattern, raw stream bytes) cost little; inside the scan kernel they ran with one or two live lanes per
+// wave and held the wave for microseconds.  The records leave block by block: one atomic on the shared counter per
+// 256 suspects -- one per wave and emit call, 10^5 to 10^6 per launch on one address at ~2 ns each, was 1.7 of
+// this kernel's 2.0 ms.
 __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
+  __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_cnt[4];
   unsigned long long n = *a.susp_count;
   if (n > a.susp_cap) n = a.susp_cap;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint4 r = a.susp[i];
-    if (r.x == PAIR_SUSPECT_HOLE) continue;
-    const uint64_t pw = ((uint64_t)r.w << 32) | r.z;
-    const int combo = (int)((pw >> 40) & 7u);
-    // the key's row of the bitmap (global copy) -> rank; its slot -> which of its patterns are within k on the other fields
-    const uint32_t key = r.x, wo = r.y, row = key & 0x7fffu, bit = key >> 15;
-    const uint32_t wd = a.image[(size_t)combo * PAIR_BITMAP_WORDS + row];
-    if (!((wd >> bit) & 1u)) continue;
-    const uint32_t lr = (uint32_t)__popc(wd & ((1u << bit) - 1u));
-    const uint32_t rank = a.row_base[(size_t)combo * (PAIR_BITMAP_WORDS + 1) + row] + lr;
-    uint32_t what = WHAT_ALL;
-    if (lr < (uint32_t)a.stride - 1u) {
-      const uint2 sl = a.slots[((size_t)combo * PAIR_BITMAP_WORDS + row) * (size_t)a.stride + lr];
-      const uint64_t S = ((uint64_t)sl.y << 32) | sl.x;
-      what = (sym_distance(((uint32_t)S ^ wo) & F20) <= a.k ? 1u : 0u) | (sym_distance(((uint32_t)(S >> 20) ^ wo) & F20) <= a.k ? 2u : 0u) |
-             (sym_distance(((uint32_t)(S >> 40) ^ wo) & F20) <= a.k ? 4u : 0u) | ((sl.y >> 31) ? WHAT_REST : 0u);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n; base += stride) {   // block-uniform trip count
+    const unsigned long long i = base + threadIdx.x;
+    pm_hit first;
+    bool have = false;
+    if (i < n) {
+      const uint4 r = a.susp[i];
+      const uint64_t pw = ((uint64_t)r.w << 32) | r.z;
+      const int combo = (int)((pw >> 40) & 7u);
+      // the key's row of the bitmap (global copy) -> rank; its slot -> which of its patterns are within k on the other fields
+      const uint32_t key = r.x, wo = r.y, row = key & 0x7fffu, bit = key >> 15;
+      const uint32_t wd = a.image[(size_t)combo * PAIR_BITMAP_WORDS + row];
+      if ((wd >> bit) & 1u) {
+        const uint32_t lr = (uint32_t)__popc(wd & ((1u << bit) - 1u));
+        const uint32_t rank = a.row_base[(size_t)combo * (PAIR_BITMAP_WORDS + 1) + row] + lr;
+        uint32_t what = WHAT_ALL;
+        if (lr < (uint32_t)a.stride - 1u) {
+          const uint2 sl = a.slots[((size_t)combo * PAIR_BITMAP_WORDS + row) * (size_t)a.stride + lr];
+          const uint64_t S = ((uint64_t)sl.y << 32) | sl.x;
+          what = (sym_distance(((uint32_t)S ^ wo) & F20) <= a.k ? 1u : 0u) | (sym_distance(((uint32_t)(S >> 20) ^ wo) & F20) <= a.k ? 2u : 0u) |
+                 (sym_distance(((uint32_t)(S >> 40) ^ wo) & F20) <= a.k ? 4u : 0u) | ((sl.y >> 31) ? WHAT_REST : 0u);
+        }
+        pair_resolve(a, combo, rank, what, wo, (int64_t)(pw & 0xffffffffffull), &first, &have);
+      }
     }
-    pair_resolve(a, combo, rank, what, wo, (int64_t)(pw & 0xffffffffffull));
+    if (a.debug & 16) have = false;
+    const unsigned long long bal = __ballot(have);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      s_base = tot ? atomicAdd(a.counter, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    if (have) {
+      unsigned long long o = s_base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) o += s_cnt[w];
+      if (o < a.cap) a.out[o] = first;
+    }
+    __syncthreads();                                                // s_cnt / s_base are rewritten by the next trip
   }
 }
 
@@ -309,7 +337,6 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   if (own_lo >= own_hi) return;
 
   const uint32_t stride = (uint32_t)a.stride, kmax = stride - 1u;   // slots per row; rank of a row's overflow marker
-  const uint32_t rowmul = 2u * stride;                              // slot bytes per row / 4 (the row comes as row * 4)
   const char *slots = reinterpret_cast<const char *>(a.slots + (size_t)combo * PAIR_BITMAP_WORDS * stride);
   // the 32 bases in front of the wave's range (wave-uniform; they enter lanes 0 and 1 through the DPP shifts)
   uint32_t carry1, carry2;
@@ -328,42 +355,18 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t q2 = ws + 2048 < own_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
   uint32_t q3 = ws + 3072 < own_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
 
-  const uint32_t m5 = 0x55555u;                                    // (v_bitop3 takes no literal: constants in SGPRs)
   const int negk1 = -(a.k + 1);
 
-  // consume stage of window I of the block whose stream words are v2 : v1 : vc: its slot E has landed.
-  // Appends the verdict (1 = suspicious) to sacc, funnelled in at the bottom: window 0 ends up at bit 15.
-  auto consume = [&](auto WIN, uint32_t v2, uint32_t v1, uint32_t vc, const u32x2 &E, uint32_t &sacc) __attribute__((always_inline)) {
-    constexpr int I = decltype(WIN)::value;
-    // the window's other fields: C at bits 0..9, D at bits 10..19 (bits above: anything)
-    uint32_t w;
-    {
-      const uint32_t X = bits_at<2 * I + 26 + 10 * C>(v2, v1, vc);
-      if constexpr (D == C + 1) w = X;
-      else { const uint32_t Y = bits_at<2 * I + 26 + 10 * D - 10>(v2, v1, vc); w = (X & 0x3ffu) | (Y & ~0x3ffu); }
-    }
-    // substitutions against each of the slot's three patterns, minus k + 1; the slot's top nibble
-    // (0 or -8: "walk") is added to the third count: negative minimum = suspicious.  Per pattern
-    // XOR, shift, (a | b) & 0x55555 (the mask also drops the bits above the 20), popcount.
-    const uint32_t x1 = E.x ^ w, x2 = __builtin_amdgcn_alignbit(E.y, E.x, 20) ^ w, x3 = (E.y >> 8) ^ w;
-    const int d1 = __popc(__builtin_amdgcn_bitop3_b32(x1, x1 >> 1, m5, 0xa8)) + negk1;
-    const int d2 = __popc(__builtin_amdgcn_bitop3_b32(x2, x2 >> 1, m5, 0xa8)) + negk1;
-    const int d3 = __popc(__builtin_amdgcn_bitop3_b32(x3, x3 >> 1, m5, 0xa8)) + (((int)E.y >> 28) + negk1);
-    const int z = min(d1, min(d2, d3));
-    sacc = __builtin_amdgcn_alignbit(sacc, (uint32_t)z, 31);
-  };
-
-  // The few windows `rem` (bit i = window i of this lane) of the block at bbase (stream words
-  // v2 : v1 : vc) that the consume stage could not dismiss become suspect records {key, other fields,
-  // position | field pair << 40} for pm_pair_verify, which works out rank and slot again with every
-  // lane busy.  They are collected in a queue of this wave in LDS and leave in batches of >= 64: any
-  // global-memory instruction on this path makes the wave wait for ALL its slot loads in flight (stores
-  // and loads share the in-order vmcnt counter, so the code behind the branch has to assume the worst)
-  // -- with the L1 fill path saturated that is a microsecond and more per suspect: 5 ms per 3 Gbp.
+  // ---- suspects ----------------------------------------------------------------------------------------
+  // Windows the consume stage cannot dismiss become suspect records {key, other fields, position |
+  // field pair << 40} for pm_pair_verify, which works out rank and slot again with every lane busy.
+  // They are collected in a queue of this wave in LDS and leave in batches of >= 64, one atomic each
+  // (same-address atomics serialise at ~2.5 ns; a dependent table read on this path held the whole
+  // wave for a microsecond per suspect: 7 ms per 3 Gbp).
   auto flush = [&]() __attribute__((always_inline)) {
     if (qn == 0) return;
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(a.susp_count, (unsigned long long)qn);   // one atomic per batch (same-address atomics serialise at ~2.5 ns each)
+    if (lane == 0) base = atomicAdd(a.susp_count, (unsigned long long)qn);
     base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
     for (int e = lane; e < qn; e += 64) {
       const u32x4 q = *lds128(QB + 16 * (uint32_t)e);
@@ -372,61 +375,114 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     }
     qn = 0;
   };
-  auto emit = [&](uint32_t v2, uint32_t v1, uint32_t vc, int64_t bbase, uint32_t rem) __attribute__((always_inline)) {
-    const uint32_t prel0 = (uint32_t)(bbase - ws) + 16 * (uint32_t)lane;
-    for (;;) {
-      const unsigned long long bal = __ballot(rem != 0);
-      if (bal == 0) break;
-      if (rem != 0) {
-        const int i = __ffs(rem) - 1;
-        rem &= rem - 1;
-        const uint32_t sft = 2 * (uint32_t)i + 26;                   // 26 .. 56: first window bit in v2 : v1 : vc
-        const uint32_t x0 = __builtin_amdgcn_alignbit(v1, v2, sft), x1 = __builtin_amdgcn_alignbit(vc, v1, sft), x2 = vc >> (sft & 31u);
-        const uint64_t W = ((uint64_t)((sft < 32 ? x1 : x2) & 0xffu) << 32) | (sft < 32 ? x0 : x1);
-        const int s_ = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-        u32x4 q;
-        q.x = field_of(W, A) | (field_of(W, B) << 10); q.y = field_of(W, C) | (field_of(W, D) << 10); q.z = prel0 + (uint32_t)i; q.w = 0;
-        if (!(a.debug & 2)) *lds128(QB + 16 * (uint32_t)s_) = q;
-      }
-      qn += __popcll(bal);
-      if (qn >= 64) { if (a.debug & 4) qn = 0; else flush(); }       // (a round adds at most 64: the queue holds 128)
+  auto enqueue = [&](bool mine, uint32_t key, uint32_t wo, uint32_t prel) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(mine);
+    if (bal == 0) return;
+    if (a.debug & 1) { keep ^= key; return; }
+    if (mine) {
+      const int s_ = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+      u32x4 q;
+      q.x = key; q.y = wo; q.z = prel; q.w = 0;
+      *lds128(QB + 16 * (uint32_t)s_) = q;
     }
+    qn += __popcll(bal);
+    if (qn >= 64) flush();                                         // (a call adds at most 64: the queue holds 128)
   };
 
-  // test stage of window I of the block whose stream words are prev2 : prev1 : cur, in two parts: the key and the
-  // read of its row of the bitmap; then -- a few windows later, when the row is there -- bit, rank in the row,
-  // and the load of the key's slot.
+  // ---- pass A: every window's key against the bitmap -----------------------------------------------------
+  // window I starts at bit 2 I + 26 of prev2 : prev1 : cur; field f at + 10 f.  The key comes out at bits 2..21.
   auto key_of = [&](auto WIN, uint32_t prev2, uint32_t prev1, uint32_t cur) __attribute__((always_inline)) -> uint32_t {
-    constexpr int I = decltype(WIN)::value;                        // window I starts at bit 2 I + 26 of prev2 : prev1 : cur; field f at + 10 f
-    const uint32_t X = bits_at<2 * I + 26 + 10 * A - 2>(prev2, prev1, cur);      // the key at bits 2..21
+    constexpr int I = decltype(WIN)::value;
+    const uint32_t X = bits_at<2 * I + 26 + 10 * A - 2>(prev2, prev1, cur);
     if constexpr (B == A + 1) return X;
     else { const uint32_t Y = bits_at<2 * I + 26 + 10 * B - 12>(prev2, prev1, cur); return (X & 0xffcu) | (Y & ~0xffcu); }
   };
-  auto slot_load = [&](uint32_t K4, uint32_t wd, u32x2 &E, uint32_t &acc) __attribute__((always_inline)) {
-    const uint32_t bit = (K4 >> 17) & 31u;                          // bits 15..19 of the key pick the bit
-    const uint32_t v = wd >> bit;
-    acc = __builtin_amdgcn_alignbit(v, acc, 1);                     // window 0 ends up at bit 16
-    // the key's slot: row * stride + rank inside the row (keys beyond the row's slots: its last slot, the overflow
-    // marker); a window whose key is absent gets row 0 -- any slot of it will do, its verdict is masked by `acc`
-    const uint32_t lr = min((uint32_t)__popc(__builtin_amdgcn_ubfe(wd, 0, bit)), kmax);
-    const uint32_t rowh = K4 & 0x1fffcu & (uint32_t)__builtin_amdgcn_sbfe((int)v, 0, 1);
-    const uint32_t off = rowh * rowmul + (lr << 3);
-    E = *reinterpret_cast<const u32x2 *>(slots + off);              // plain load: nontemporal ran 3x, sc1 1.7x slower
+
+  // ---- pass B: the windows whose key occurs, one per lane and round ---------------------------------------
+  // 17 % of the windows are key hits; what is done for them -- rank in the row, slot address, the 8-byte load,
+  // three XOR + popcount against the slot's patterns -- costs ~60 vector-instruction slots, four times the
+  // membership test, and VALU issue is what this kernel is bound by: most of the integer instructions it is
+  // made of (every three-operand form, v_bcnt, v_bfe, v_alignbit, anything with an SGPR operand) issue at HALF the
+  // rate of v_and / v_xor / v_add / shifts by a constant on gfx950 (scripts/probe/valu_rate.hip).  Done branch-free
+  // for all 16 windows of a lane the kernel took 17.7 ms per 3 Gbp.  So the hits are processed in ROUNDS instead:
+  // per round every lane takes its oldest pending hit.  Pending hits are a 32-bit mask per lane -- bits 0..15 the
+  // previous block's windows, 16..31 this block's -- so a lane with many hits in one block works them off while
+  // its neighbours idle only for what exceeds two blocks' worth: a block takes RMIN rounds, more only while some
+  // lane still has hits of the previous block (whose stream words are about to be dropped).
+  // A round is a three-stage software pipeline over the lane's hits (registers: see NR below):
+  //   stage 1  next pending window -> its 40 bits (two v_alignbit by 2 i on the block's pre-shifted words) -> key,
+  //            other fields, position; read the key's row of the bitmap again (LDS);
+  //   stage 2  (one round later) rank inside the row -> slot address -> global_load_dwordx2;
+  //   stage 3  (five rounds later) the slot's three patterns against the window's other 20 bits; the few that
+  //            stay suspicious (or need the key's pattern list walked) are queued for the verify kernel.
+  // Lanes without a pending hit run along with key 0 (row 0: one cached line) and their verdict masked.
+  // The pipeline's registers are a ring of NR entries with compile-time indices (round<PH> is instantiated for
+  // PH = 0 .. NR-1 and rounds run in pairs, so nothing is ever moved): round t works on entry t mod NR three times --
+  // stage 3 consumes it (filled NR rounds ago, its slot loaded NR - 1 rounds ago), stage 1 refills it; stage 2 loads the
+  // slot of the entry filled last round.  NR - 1 = 5 slot loads in flight per lane.
+  constexpr int NR = 6;
+  uint32_t P = 0;                                                   // pending key hits: bits 0..15 previous block, 16..31 current block
+  uint32_t pu1 = 0, pu2 = 0, pu3 = 0, cu1 = 0, cu2 = 0, cu3 = 0;       // stream bits 26..57 / 58..89 / 90..95 of the previous / current block's word triple
+  uint32_t prel_p = 0, prel_c = 0;                                  // position of the lane's window 0 relative to ws, previous / current block
+  u32x2 e_sl[NR];                                                   // slot
+  uint32_t e_key[NR], e_wo[NR], e_rel[NR], e_okm[NR], e_wd[NR];       // key, other fields, position, validity (sign bit), the key's row of the bitmap
+#pragma unroll
+  for (int d = 0; d < NR; ++d) { e_sl[d].x = 0; e_sl[d].y = 0; e_key[d] = e_wo[d] = e_rel[d] = e_okm[d] = e_wd[d] = 0; }
+  uint32_t m5v, f20v, rowmask;                                      // constants in VGPRs: an SGPR or literal operand halves the issue rate of v_and
+  asm volatile("v_mov_b32 %0, 0x55555\n v_mov_b32 %1, 0xfffff\n v_mov_b32 %2, 0x7fff" : "=v"(m5v), "=v"(f20v), "=v"(rowmask));
+
+  auto round = [&](auto PHASE) __attribute__((always_inline)) {
+    constexpr int PH = decltype(PHASE)::value, LD = (PH + NR - 1) % NR;
+    // stage 3: entry PH, whose slot was loaded NR - 1 rounds ago: substitutions against each of the slot's three
+    // patterns minus k + 1; the slot's top nibble (0 or -8: "walk") is added to the third count; a negative one =
+    // suspicious (if the entry holds a window at all)
+    {
+      const uint32_t w = e_wo[PH];
+      const uint32_t x1 = e_sl[PH].x ^ w, x2 = __builtin_amdgcn_alignbit(e_sl[PH].y, e_sl[PH].x, 20) ^ w, x3 = (e_sl[PH].y >> 8) ^ w;
+      const int d1 = __popc((x1 | (x1 >> 1)) & m5v) + negk1;
+      const int d2 = __popc((x2 | (x2 >> 1)) & m5v) + negk1;
+      const int d3 = __popc((x3 | (x3 >> 1)) & m5v) + (((int)e_sl[PH].y >> 28) + negk1);
+      const bool susp = (int)((uint32_t)(d1 | d2 | d3) & e_okm[PH]) < 0;
+      enqueue(susp, e_key[PH], w, e_rel[PH]);
+    }
+    // stage 2: entry LD, filled last round: rank of its key inside the row -> slot (keys beyond the row's slots: its
+    // last slot, the overflow marker)
+    {
+      const uint32_t bit = e_key[LD] >> 15;
+      const uint32_t lr = min((uint32_t)__popc(__builtin_amdgcn_ubfe(e_wd[LD], 0, bit)), kmax);
+      const uint32_t off = (__umul24(e_key[LD] & rowmask, stride) + lr) << 3;
+      e_sl[LD] = *reinterpret_cast<const u32x2 *>(slots + off);       // plain load: nontemporal ran 3x, sc1 1.7x slower
+    }
+    // stage 1: the lane's oldest pending hit into entry PH
+    {
+      uint32_t i;                                                     // lowest pending window, -1 when nothing is pending
+      asm("v_ffbl_b32 %0, %1" : "=v"(i) : "v"(P));
+      P &= P - 1u;
+      const uint32_t okm = ~i;                                        // sign bit: the entry holds a window
+      const bool cb = (i & 16u) != 0;                                 // window of the current block?
+      const uint32_t j2 = i << 1;                                     // (v_alignbit takes the low five bits: 2 (i & 15))
+      const uint32_t u1 = cb ? cu1 : pu1, u2 = cb ? cu2 : pu2, u3 = cb ? cu3 : pu3;
+      const uint32_t wlo = __builtin_amdgcn_alignbit(u2, u1, j2), whi = __builtin_amdgcn_alignbit(u3, u2, j2);   // window bits 0..31, 32..39 (+ junk above)
+      // 20 bits from window bit O (O = 0, 10, 20; junk above bit 19 unless masked)
+      auto from = [&](int O) __attribute__((always_inline)) -> uint32_t { return O == 0 ? wlo : (O == 10 ? wlo >> 10 : __builtin_amdgcn_alignbit(whi, wlo, 20)); };
+      uint32_t key, wo;
+      if constexpr (B == A + 1) key = from(10 * A) & f20v; else key = (from(10 * A) & 0x3ffu) | (from(10 * B - 10) & 0xffc00u);
+      if constexpr (D == C + 1) wo = from(10 * C) & f20v; else wo = (from(10 * C) & 0x3ffu) | (from(10 * D - 10) & 0xffc00u);
+      key &= (uint32_t)((int)okm >> 31);                              // no window: key 0 (row 0: one cached line)
+      e_key[PH] = key; e_wo[PH] = wo; e_okm[PH] = okm;
+      e_rel[PH] = (cb ? prel_c : prel_p) + (i & 15u);
+      e_wd[PH] = *lds32((key & rowmask) << 2);
+    }
+  };
+  int ph = 0;                                                       // wave-uniform: next pair of ring entries
+  auto two_rounds = [&]() __attribute__((always_inline)) {
+    if (ph == 0) { round(std::integral_constant<int, 0>()); round(std::integral_constant<int, 1>()); ph = 1; }
+    else if (ph == 1) { round(std::integral_constant<int, 2>()); round(std::integral_constant<int, 3>()); ph = 2; }
+    else { round(std::integral_constant<int, 4>()); round(std::integral_constant<int, 5>()); ph = 0; }
   };
 
-  // Software pipeline, one window at a time.  Step I of a block: read the bitmap row of window I + AHEAD; consume
-  // the slot of window I of the PREVIOUS block (loaded 16 steps ago) and, into the same two registers, load the
-  // slot of window I of this block.  So every wave always has 16 slot loads in flight and issues them one by one,
-  // ~35 vector instructions apart, instead of eight in a row followed by 300 instructions without any: a burst
-  // fills the CU's miss queue, the next wave's loads then stall at issue with its vector work stuck behind them,
-  // and fill path and VALU take turns instead of overlapping (half-block bursts: 18.7 ms per 3 Gbp).
-  // sched_barrier keeps the compiler from re-clustering the loads.
-  constexpr int AHEAD = 3;
-  u32x2 E[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { E[i].x = 0; E[i].y = 0; }
-  uint32_t pv2 = 0, pv1 = 0, pvc = 0, prem = 0;                     // previous block: stream words, bitmap survivors among the owned windows
-  int64_t pbb = ws, bb = ws;
+  int64_t bb = ws;
+  const int rmin = (a.debug >> 8) & 15 ? (a.debug >> 8) & 15 : 2;   // rounds per block at least (measurement knob in the debug word)
   while (bb < own_hi) {
     const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
@@ -443,39 +499,31 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const uint32_t l = lo <= 0 ? 0u : (lo >= 16 ? 16u : (uint32_t)lo), hh = hi <= 0 ? 0u : (hi >= 16 ? 16u : (uint32_t)hi);
       own = ((1u << hh) - 1u) & ~((1u << l) - 1u);
     }
-    uint32_t acc = 0, sacc = 0;
-    uint32_t ks[16], wd[16];
-    for_windows(std::make_integer_sequence<int, AHEAD>(), [&](auto WIN) __attribute__((always_inline)) {
-      constexpr int I = decltype(WIN)::value;
-      ks[I] = key_of(WIN, prev2, prev1, cur);
-      wd[I] = *lds32(ks[I] & 0x1fffcu);
-    });
-    for_windows(std::make_integer_sequence<int, 16>(), [&](auto WIN) __attribute__((always_inline)) {
-      constexpr int I = decltype(WIN)::value;
-      if constexpr (I + AHEAD < 16) {
-        ks[I + AHEAD] = key_of(std::integral_constant<int, I + AHEAD>(), prev2, prev1, cur);
-        wd[I + AHEAD] = *lds32(ks[I + AHEAD] & 0x1fffcu);
-      }
-      consume(WIN, pv2, pv1, pvc, E[I], sacc);
-      slot_load(ks[I], wd[I], E[I], acc);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    {                                                               // the previous block is complete now
-      const uint32_t slow = (__brev(sacc) >> 16) & prem;
-      if (__ballot(slow != 0)) { if (a.debug & 1) keep ^= slow; else emit(pv2, pv1, pvc, pbb, slow); }
+    // pass A: 16 membership tests (key, row of the bitmap, bit), the bits funnelled into acc from the top
+    uint32_t acc = 0;
+    {
+      uint32_t ks[16], wd[16];
+      for_windows(std::make_integer_sequence<int, 16>(), [&](auto WIN) __attribute__((always_inline)) {
+        constexpr int I = decltype(WIN)::value;
+        ks[I] = key_of(WIN, prev2, prev1, cur);
+        wd[I] = *lds32(ks[I] & 0x1fffcu);
+      });
+      for_windows(std::make_integer_sequence<int, 16>(), [&](auto WIN) __attribute__((always_inline)) {
+        constexpr int I = decltype(WIN)::value;
+        acc = __builtin_amdgcn_alignbit(wd[I] >> ((ks[I] >> 17) & 31u), acc, 1);   // bits 15..19 of the key pick the bit; window 0 ends up at bit 16
+      });
     }
-    pv2 = prev2; pv1 = prev1; pvc = cur; prem = (acc >> 16) & own; pbb = bb;
+    P |= acc & (own << 16);
+    cu1 = __builtin_amdgcn_alignbit(prev1, prev2, 26); cu2 = __builtin_amdgcn_alignbit(cur, prev1, 26); cu3 = cur >> 26;
+    prel_c = (uint32_t)(bb - ws) + 16 * (uint32_t)lane;
+    // pass B
+    int r = 0;
+    do { two_rounds(); r += 2; } while (r < rmin || __ballot((P & 0xffffu) != 0));
+    P >>= 16; pu1 = cu1; pu2 = cu2; pu3 = cu3; prel_p = prel_c;
     bb += 1024;
   }
-  {                                                                 // the last block's slots
-    uint32_t sacc = 0;
-    for_windows(std::make_integer_sequence<int, 16>(), [&](auto WIN) __attribute__((always_inline)) {
-      constexpr int I = decltype(WIN)::value;
-      consume(WIN, pv2, pv1, pvc, E[I], sacc);
-    });
-    const uint32_t slow = (__brev(sacc) >> 16) & prem;
-    if (__ballot(slow != 0)) { if (a.debug & 1) keep ^= slow; else emit(pv2, pv1, pvc, pbb, slow); }
-  }
+  while (__ballot(P != 0)) two_rounds();                            // what the last block left
+  for (int d = 0; d < NR / 2 + 1; ++d) two_rounds();                // and what is still in the pipeline
   if (keep == 0x9e3779b9u) a.susp[0] = make_uint4(keep, 0, 0, 0);   // (measurement switch: the verdicts must stay alive)
   flush();
 }
@@ -707,7 +755,9 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   hipLaunchKernelGGL(pm_pair_scan, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
   hipError_t ce = hipGetLastError();
   if (ce != hipSuccess) return ce;
-  hipLaunchKernelGGL(pm_pair_verify, dim3(256 * 16), dim3(256), 0, st, a);
+  // one suspect per thread for up to 8 Mi of them (the count is on the device): the verify is a chain of ~8 dependent
+  // table and stream reads per suspect; six suspects per thread one after the other made every wave live 0.9 ms
+  hipLaunchKernelGGL(pm_pair_verify, dim3(32768), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
