@@ -225,11 +225,16 @@ def measured_traffic(args, shard):
 def issue_roofline(args, shard, kms):
     """SURVEY 8(d) "honest secondary bound" for the seed family: the kernels are not HBM bound; which on-chip
     pipe is how busy, from the committed PMC passes of this exact workload (profiles/issue_r*.json, made by
-    scripts/pmc_issue.sh) and THIS run's kernel time:
-      valu  = VALU wave-instructions / (256 CUs x 4 SIMDs x kernel cycles / 2): a wave64 VALU instruction holds its SIMD-32 for 2 cycles
+    scripts/pmc_issue.sh) and THIS run's kernel time, at the 2.4 GHz peak clock (the chip runs ~2.05 GHz under
+    these kernels, so every fraction is a lower bound):
+      valu  = VALU wave-instructions x cycles per instruction / (256 CUs x 4 SIMDs x kernel cycles).  gfx950 issues
+              v_and/v_or/v_xor/v_add/v_sub/v_lshrrev/v_mov at one wave64 instruction per ~2 cycles and SIMD, but every
+              three-operand (VOP3) form, v_bcnt, v_bfe, v_alignbit, v_min/max, v_mul_u32_u24, left shifts, SDWA / DPP
+              forms and anything with an SGPR operand at one per ~4 (profiles/r03_probe_valu_rate.txt): both bounds given;
+              these kernels are mostly made of the second kind
       lds   = LDS-array active cycles (incl. bank conflicts), summed over the CUs / (256 x kernel cycles)
-      l1_l2 = L1 -> L2 read requests (one 128-byte line each) / (256 CUs x 0.5 lines per cycle: the 64 B/clk L2 -> L1 return path)
-    at the 2.4 GHz peak clock (the chip clocks lower under load, so the fractions are lower bounds)."""
+      l1_l2 = L1 -> L2 read requests (one 128-byte line each) x 2 cycles / (256 CUs x kernel cycles): the L2 -> L1
+              return path moves 64 B per clock and CU (269 G lines/s for the chip, profiles/r03_probe_tcp_gather.txt)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "issue_r*.json"))):
@@ -241,15 +246,21 @@ def issue_roofline(args, shard, kms):
         return None
     e, src = best
     cyc = kms * 1e-3 * 2.4e9
-    out = {"source": src, "kernel": e.get("kernel"), "clock_ghz": 2.4, "kernel_ms": kms}
+    out = {"source": src, "kernel": e.get("kernel"), "clock_ghz": 2.4, "kernel_ms": kms,
+           "note": "counters of the scan kernel alone; kernel_ms (HIP events) also holds the verify kernel behind it"}
+    fr = {}
     if e.get("SQ_INSTS_VALU"):
-        out["valu"] = {"wave_instructions": e["SQ_INSTS_VALU"], "frac": e["SQ_INSTS_VALU"] / (256 * 4 * cyc / 2)}
+        out["valu"] = {"wave_instructions": e["SQ_INSTS_VALU"], "frac_if_all_full_rate": e["SQ_INSTS_VALU"] * 2 / (256 * 4 * cyc),
+                       "frac_if_all_half_rate": e["SQ_INSTS_VALU"] * 4 / (256 * 4 * cyc)}
+        fr["valu"] = out["valu"]["frac_if_all_half_rate"]
     if e.get("SQ_LDS_IDX_ACTIVE"):
         out["lds"] = {"active_cycles": e["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": e.get("SQ_LDS_BANK_CONFLICT"),
                       "frac": e["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)}
+        fr["lds"] = out["lds"]["frac"]
     if e.get("TCP_TCC_READ_REQ_sum"):
-        out["l1_l2"] = {"read_requests": e["TCP_TCC_READ_REQ_sum"], "frac": e["TCP_TCC_READ_REQ_sum"] / (256 * 0.5 * cyc)}
-    fr = {k: v["frac"] for k, v in out.items() if isinstance(v, dict)}
+        out["l1_l2"] = {"read_requests": e["TCP_TCC_READ_REQ_sum"], "l2_misses": e.get("TCC_MISS_sum"),
+                        "frac": e["TCP_TCC_READ_REQ_sum"] * 2 / (256 * cyc)}
+        fr["l1_l2"] = out["l1_l2"]["frac"]
     if fr:
         out["binding"] = max(fr, key=fr.get)
     return out

@@ -34,6 +34,11 @@ __global__ __launch_bounds__(1024) void NAME(int iters, uint32_t *out) { \
 #define ABIT(X) X ", %8, %10 bitop3:0xa8"
 #define ALSA(X) X ", 3, %8"
 #define ADPP(X) X " wave_shr:1"
+#define ALIT(X) "0x1fffc, " X
+#define ALITB(X) "0x55555555, " X
+#define AVSH(X) "%8, " X
+#define ASH17(X) "17, " X
+#define ACND(X) X ", %8, vcc"
 #define ASDWA(X) "%8, " X " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
 
 KERNEL(k_xor, I8("v_xor_b32", A2))
@@ -68,6 +73,18 @@ KERNEL(k_andor, I8("v_and_or_b32", A3))
 KERNEL(k_ashr, I8("v_ashrrev_i32", ASH))
 KERNEL(k_ffbl, I8("v_ffbl_b32", A1))
 KERNEL(k_cvt, I8("v_cvt_f32_u32", A1))
+KERNEL(k_and_lit, I8("v_and_b32", ALIT))
+KERNEL(k_and_lit2, I8("v_and_b32", ALITB))
+KERNEL(k_xor_lit, I8("v_xor_b32", ALITB))
+KERNEL(k_lshr_v, I8("v_lshrrev_b32", AVSH))
+KERNEL(k_lshl_v, I8("v_lshlrev_b32", AVSH))
+KERNEL(k_or, I8("v_or_b32", A2))
+KERNEL(k_sub, I8("v_sub_u32", A2))
+KERNEL(k_cnd, I8("v_cndmask_b32", ACND))
+KERNEL(k_not, I8("v_not_b32", A1))
+KERNEL(k_lshl17, I8("v_lshlrev_b32", ASH17))
+KERNEL(k_max, I8("v_max_u32", A2))
+KERNEL(k_addi, I8("v_add_u32", ASH17))
 
 template <typename K>
 void run(const char *name, K kern, uint32_t *d_out, int lds_bytes, int blocks_per_cu) {
@@ -92,7 +109,7 @@ int main() {
 #define R(K) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); run(#K, K, d_out, 150 * 1024, 4);
   R(k_xor) R(k_and) R(k_add) R(k_and_s) R(k_lshr) R(k_lshrv) R(k_mov) R(k_bcnt) R(k_bfe) R(k_bfev) R(k_align) R(k_alignv) R(k_bitop3) R(k_bfi)
   R(k_min) R(k_min3) R(k_or3) R(k_add3) R(k_xad) R(k_lsa) R(k_mul24) R(k_mad24) R(k_mullo) R(k_perm) R(k_dpp) R(k_sdwa) R(k_fma) R(k_pkadd) R(k_andor)
-  R(k_ashr) R(k_ffbl) R(k_cvt)
+  R(k_ashr) R(k_ffbl) R(k_cvt) R(k_and_lit) R(k_and_lit2) R(k_xor_lit) R(k_lshr_v) R(k_lshl_v) R(k_or) R(k_sub) R(k_cnd) R(k_not) R(k_lshl17) R(k_max) R(k_addi)
   printf("-- two workgroups of 1024 per CU (8 waves per SIMD):\n");
 #define R2(K) run(#K, K, d_out, 64 * 1024, 8);
   R2(k_xor) R2(k_alignv) R2(k_bitop3) R2(k_bcnt) R2(k_fma)

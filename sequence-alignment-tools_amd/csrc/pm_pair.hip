@@ -616,8 +616,10 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
   const int C = t.ncombos;
   // Slots per row of the slot table: rows (32 keys each) hold a Poisson number of the keys that occur, 5.5 on
   // average at 200k patterns; the last slot of a row is its overflow marker.  12 slots = 96 bytes per row keep
-  // a field pair's table at 3 MiB -- inside an XCD's 4 MiB of L2 -- with 0.3 % of the keys beyond their row.
-  t.stride = stride_knob >= 2 && stride_knob <= 33 ? stride_knob : 12;
+  // a field pair's table at 3 MiB -- inside an XCD's 4 MiB of L2 -- with 0.3 % of the keys beyond their row
+  // (3 Gbp x 200k patterns: 12 slots 14.8 ms, 14: 15.2, 16: 16.9 -- L2 misses; 10: 21.8 -- overflow suspects);
+  // fuller tiles (the 250k-pattern tiles of a 10^6-primer set: 6.9 keys per row) take 14.
+  t.stride = stride_knob >= 2 && stride_knob <= 33 ? stride_knob : (np <= 230000 ? 12 : (np <= 300000 ? 14 : 16));
   const size_t ST = (size_t)t.stride, KMAX = ST - 1;
   t.image.assign((size_t)C * PAIR_BITMAP_WORDS, 0);
   t.order.assign((size_t)C * np, 0);
@@ -716,8 +718,12 @@ void pair_free(PairDevice *d) {
 ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end) {
   ScanGeometry g;
   int64_t chunk = 1 << 19;                                         // 512 Ki positions per workgroup
-  // large ranges: 2 Mi positions per workgroup amortise staging the 128 KiB LDS image
-  if ((end - begin) / ((int64_t)1 << 21) * d.ncombos >= 256 * 8) chunk = (int64_t)1 << 21;
+  // large ranges: 1 Mi or 2 Mi positions per workgroup amortise staging the 128 KiB bitmap and the pipeline's fill and
+  // drain, as long as the grid still has many workgroups per CU for its tail (3 Gbp: -K 2, 6 field pairs, 2 Mi: 8586
+  // workgroups; -K 1, 2 field pairs: 5.23 ms with 1 Mi against 5.38 with 2 Mi and 5.36 with 512 Ki)
+  const int64_t range = end - begin;
+  if (range / ((int64_t)1 << 21) * d.ncombos >= 256 * 24) chunk = (int64_t)1 << 21;
+  else if (range / ((int64_t)1 << 20) * d.ncombos >= 256 * 8) chunk = (int64_t)1 << 20;
   if (d.knobs.seed_chunk >= 1024 * WAVES) chunk = d.knobs.seed_chunk / (1024 * WAVES) * (1024 * WAVES);   // test knob (shared with the seed kernels)
   g.seg_len = chunk;
   const int64_t c_lo = begin / chunk, c_hi = end > begin ? (end - 1) / chunk : c_lo - 1;

@@ -263,12 +263,12 @@ def test_edit_distance_three_gbp_100k_primers():
     key, kk = hit_index(hits)
     for i, (_, a, sl, d) in enumerate(plant):
         assert found(key, kk, i + 1, a + sl, 2 * k + 1 + d, d), ("planted primer not found", i, a, d)
-    assert hits.size > 2_000_000, hits.size
+    assert hits.size > 100_000, hits.size                           # (22-mers: ~3e5 chance hits within two edits per 3 Gbp x 200k patterns)
     bp = engine(allp, k, sat_amd.KERNEL_BITPAR, dev, indels=True)
     lo = (1 << 31) + (1 << 26)
     a = np.sort(pm.scan_candidates(lo, lo + (1 << 21)), order=["end", "pid", "k"])
     b = np.sort(bp.scan_candidates(lo, lo + (1 << 21)), order=["end", "pid", "k"])
-    assert a.size > 1000 and a.size == b.size and (a["end"] == b["end"]).all() and (a["pid"] == b["pid"]).all() and (a["k"] == b["k"]).all(), (a.size, b.size)
+    assert a.size > 300 and a.size == b.size and (a["end"] == b["end"]).all() and (a["pid"] == b["pid"]).all() and (a["k"] == b["k"]).all(), (a.size, b.size)
     pm.close()
     bp.close()
 
