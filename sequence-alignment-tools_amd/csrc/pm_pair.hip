@@ -14,32 +14,34 @@
 //   * a WORKGROUP owns one (field pair, stream chunk): it stages that pair's key bitmap in LDS (key
 //     bits 0..14 = ROW = dword, bits 15..19 = bit), then streams its chunk of the 2-bit packed stream;
 //   * a LANE owns 16 consecutive window positions per block of 1024; its two predecessors' dwords
-//     come in by two whole-wave DPP shifts.  Everything that runs for every window is straight-line
-//     code with compile-time window offsets:
-//       test     key (one or two v_alignbit + v_bfi), one ds_read_b32 of the key's row.  The row
-//                gives the key's bit AND, for free, its rank inside the row (popcount of the lower
-//                bits): the keys that occur own consecutive 8-byte slots of a table in L2 -- `stride`
-//                slots per row -- so (row, rank in row) addresses the key's slot without any rank
-//                directory: one global_load_dwordx2 per window, branch-free (windows whose key does
-//                not occur, 83 % at 200k patterns, read a slot of row 0: one cached line);
-//       consume  one block later, when the loads have landed: the slot holds the OTHER 20 window bits
-//                of up to three patterns with this key; three XOR + popcount against the window's own
-//                other fields decide the window.  What survives is a true candidate on the packed
-//                bases (1e-3 of the positions), a key with more than three patterns, or a key beyond
-//                its row's slots (0.3 % of the keys at 200k patterns: row occupancy is Poisson);
-//   * those few go -- by a divergent path that recomputes what it needs -- to a suspect list; a second
-//     kernel, pm_pair_verify, reads the raw stream bytes for the exact distance (N = mismatch, EOS =
-//     reject) with every lane busy;
+//     come in by two whole-wave DPP shifts;
+//       pass A   for every window, straight-line code with compile-time offsets: key (v_lshrrev /
+//                v_alignbit, v_bfi for separated fields), one ds_read_b32 of the key's ROW of the bitmap,
+//                the key's bit funnelled into a mask of the lane's pending key hits (5 instructions);
+//       pass B   only for the key hits (17 % of the windows at 200k patterns), in ROUNDS: per round every
+//                lane takes its oldest pending hit (hits of two blocks are pending at a time).  The row
+//                gives, besides the key's bit, its rank inside the row (popcount of the lower bits): the
+//                keys that occur own consecutive 8-byte slots of a table in L2 -- `stride` slots per row --
+//                so (row, rank in row) addresses the key's slot without any rank directory: one
+//                global_load_dwordx2.  The slot holds the OTHER 20 window bits of up to three patterns
+//                with this key; three XOR + popcount against the window's own other fields decide the
+//                window, five rounds later.  What survives is a true candidate on the packed bases
+//                (1e-3 of the positions), a key with more than three patterns, or a key beyond its
+//                row's slots (0.3 % of the keys at 200k patterns: row occupancy is Poisson);
+//   * those few are queued per wave in LDS and leave in batches for a suspect list; a second kernel,
+//     pm_pair_verify, works out rank and slot again and reads the raw stream bytes for the exact
+//     distance (N = mismatch, EOS = reject) with every lane busy;
 //   * a (window, pattern) pair that agrees on several field pairs is reported by the first of them
 //     in the plan's list.
 //
-// What bounds it (3 Gbp, 200k patterns, k = 2; scripts/probe/tcp_gather.hip, profiles/): every key hit
-// (17.4 % of 1.8e10 tests) is a random 128-byte line from L2 into a CU's L1, and that path moves one
-// line per ~2 cycles and CU -- 269 G lines/s for the chip = the 34 TB/s of L2 bandwidth -- whatever
-// the bytes asked for: 3.1e9 lines = 11.5 ms.  Round 2's form of this kernel paid a second such line
-// (rank-indexed exact table) for the 2.3 % of the windows its 2-byte direct table could not settle,
-// plus the rank directory, a wave queue and the compaction in front of it; here a key hit costs
-// exactly one line.
+// What bounds it (3 Gbp, 200k patterns, k = 2; scripts/probe/, profiles/r03_*): VALU issue.  Most of the
+// integer instructions this code is made of (every VOP3 form, v_bcnt, v_bfe, v_alignbit, left shifts,
+// anything with an SGPR operand) issue at one wave64 instruction per ~4 cycles and SIMD, half the rate of
+// v_and / v_add / right shifts: 7.2e9 of them per launch = 0.78 of that capacity.  Beside it every key hit
+// (17.4 % of 1.8e10 tests) is a random 128-byte line from L2 into a CU's L1 -- that path moves one line per
+// ~2 cycles and CU, 269 G lines/s for the chip, whatever the bytes asked for: 3.1e9 lines = 0.68 of it.
+// Round 2's form paid a second such line (rank-indexed exact table) for the 2.3 % of the windows its 2-byte
+// direct table could not settle, and did the rank / address / compare work branch-free for all windows.
 #include "pm_internal.h"
 #include "pm_pair.h"
 
