@@ -369,7 +369,9 @@ def main():
     own_path = use_dist and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC
     g_lo = 0 if glo == 0 else begin - GUARD
     g_hi = stream.numel() if ghi == total else end + GUARD
-    land_stream = torch.cuda.Stream(device=dev) if rank == 0 and own_path else None
+    land_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
+    one_pin = torch.empty((1 << 24) * 2, dtype=torch.int64, pin_memory=True) if rank == 0 and not use_dist else None
+    landed = [None, False]                                          # single rank: event of the copy in flight; does it read the candidate buffer itself?
     all_pin = torch.empty((1 << 24) * 2 * (world if own_path else 1), dtype=torch.int64, pin_memory=True) if rank == 0 and own_path else None
     dev_final = [True]                                              # GPU clustering available for this option set?
 
@@ -487,6 +489,9 @@ def main():
         if own_path:
             return step_owned()
         if not use_dist:
+            cur = torch.cuda.current_stream()
+            if landed[0] is not None and landed[1]:
+                cur.wait_event(landed[0])                             # the copy in flight reads the record buffer this scan writes
             while True:
                 ncand, need = scan(begin, end)
                 if not need:
@@ -494,6 +499,30 @@ def main():
                 grow(need)
             ptr, cnt = pm.candidates_device()
             cand_count[0] = cnt
+            if dev_final[0] and cnt >= (1 << 16):                     # (a few thousand records: the plain copy is cheaper than the stream hand-over)
+                # final hits stay in HBM (pm_final_hits_device); their copy into pinned host memory runs on a side
+                # stream beside the NEXT step's scan (the timed region ends with a device-wide synchronize, so the
+                # last copy is inside it)
+                try:
+                    if landed[0] is not None:
+                        cur.wait_event(landed[0])                     # the finalize stage reuses the buffer the copy in flight reads
+                    fptr, fcnt = pm.finalize_device(end, last=True, sort=False, d_cands=ptr, n=cnt, keep=True)
+                    if fcnt * 2 > one_pin.numel():
+                        raise SystemExit("bench.py: more final hits than the host landing zone holds")
+                    land_stream.wait_stream(cur)
+                    with torch.cuda.stream(land_stream):
+                        if fcnt:
+                            one_pin[:fcnt * 2].copy_(torch.as_tensor(CudaArray(fptr, fcnt * 16), device=dev).view(torch.int64), non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(land_stream)
+                    landed[0], landed[1] = ev, fptr == ptr
+                    last_final[0] = one_pin[:fcnt * 2]
+                    final_hits[0] = fcnt
+                    return ncand
+                except sat_amd.PmError as e:
+                    if e.code != -2:
+                        raise
+                    dev_final[0] = False
             last_final[0] = finalize_rank0(ptr, cnt, end)
             final_hits[0] = last_final[0].size
             return ncand

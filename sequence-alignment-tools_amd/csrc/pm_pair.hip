@@ -422,7 +422,11 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   // PH = 0 .. NR-1 and rounds run in pairs, so nothing is ever moved): round t works on entry t mod NR three times --
   // stage 3 consumes it (filled NR rounds ago, its slot loaded NR - 1 rounds ago), stage 1 refills it; stage 2 loads the
   // slot of the entry filled last round.  NR - 1 = 5 slot loads in flight per lane.
-  constexpr int NR = 6;
+#ifndef PM_PAIR_NR
+#define PM_PAIR_NR 6
+#endif
+  constexpr int NR = PM_PAIR_NR;
+  static_assert(NR % 2 == 0 && NR >= 4 && NR <= 12, "ring size");
   uint32_t P = 0;                                                   // pending key hits: bits 0..15 previous block, 16..31 current block
   uint32_t pu1 = 0, pu2 = 0, pu3 = 0, cu1 = 0, cu2 = 0, cu3 = 0;       // stream bits 26..57 / 58..89 / 90..95 of the previous / current block's word triple
   uint32_t prel_p = 0, prel_c = 0;                                  // position of the lane's window 0 relative to ws, previous / current block
@@ -478,9 +482,15 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   };
   int ph = 0;                                                       // wave-uniform: next pair of ring entries
   auto two_rounds = [&]() __attribute__((always_inline)) {
-    if (ph == 0) { round(std::integral_constant<int, 0>()); round(std::integral_constant<int, 1>()); ph = 1; }
-    else if (ph == 1) { round(std::integral_constant<int, 2>()); round(std::integral_constant<int, 3>()); ph = 2; }
-    else { round(std::integral_constant<int, 4>()); round(std::integral_constant<int, 5>()); ph = 0; }
+    bool done = false;
+    for_windows(std::make_integer_sequence<int, NR / 2>(), [&](auto Q) __attribute__((always_inline)) {
+      constexpr int q = decltype(Q)::value;
+      if (!done && ph == q) {
+        round(std::integral_constant<int, 2 * q>()); round(std::integral_constant<int, 2 * q + 1>());
+        ph = q + 1 == NR / 2 ? 0 : q + 1;
+        done = true;
+      }
+    });
   };
 
   int64_t bb = ws;

@@ -42,7 +42,8 @@ class _Config(C.Structure):
 
 
 def library_path():
-    return os.path.join(_CSRC, "libpm_gpu.so")
+    # PM_GPU_LIB: A/B measurements of another build of the same library (never a different implementation)
+    return os.environ.get("PM_GPU_LIB") or os.path.join(_CSRC, "libpm_gpu.so")
 
 
 def build_library(force=False):
