@@ -481,6 +481,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     }
   };
   int ph = 0;                                                       // wave-uniform: next pair of ring entries
+  int quiet = NR + 1;                                               // wave-uniform: rounds run since a lane last had a hit pending (> NR: the pipeline is empty)
   auto two_rounds = [&]() __attribute__((always_inline)) {
     bool done = false;
     for_windows(std::make_integer_sequence<int, NR / 2>(), [&](auto Q) __attribute__((always_inline)) {
@@ -528,9 +529,13 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     P |= acc & (own << 16);
     cu1 = __builtin_amdgcn_alignbit(prev1, prev2, 26); cu2 = __builtin_amdgcn_alignbit(cur, prev1, 26); cu3 = cur >> 26;
     prel_c = (uint32_t)(bb - ws) + 16 * (uint32_t)lane;
-    // pass B
-    int r = 0;
-    do { two_rounds(); r += 2; } while (r < rmin || __ballot((P & 0xffffu) != 0));
+    // pass B (skipped while no lane has a hit pending and the pipeline has run empty: sparse pattern sets)
+    if (__ballot(P != 0)) quiet = 0;
+    if (quiet <= NR) {
+      int r = 0;
+      do { two_rounds(); r += 2; } while (r < rmin || __ballot((P & 0xffffu) != 0));
+      quiet += r;
+    }
     P >>= 16; pu1 = cu1; pu2 = cu2; pu3 = cu3; prel_p = prel_c;
     bb += 1024;
   }
@@ -730,12 +735,13 @@ void pair_free(PairDevice *d) {
 ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end) {
   ScanGeometry g;
   int64_t chunk = 1 << 19;                                         // 512 Ki positions per workgroup
-  // large ranges: 1 Mi or 2 Mi positions per workgroup amortise staging the 128 KiB bitmap and the pipeline's fill and
-  // drain, as long as the grid still has many workgroups per CU for its tail (3 Gbp: -K 2, 6 field pairs, 2 Mi: 8586
-  // workgroups; -K 1, 2 field pairs: 5.23 ms with 1 Mi against 5.38 with 2 Mi and 5.36 with 512 Ki)
+  // larger ranges: 1 Mi or 2 Mi positions per workgroup amortise staging the 128 KiB bitmap and the pipeline's fill and
+  // drain, as long as the grid keeps >= 16 workgroups per CU for its tail (3 Gbp: -K 2, 6 field pairs, 2 Mi = 8586
+  // workgroups; -K 1, 2 field pairs: 5.23 ms with 1 Mi against 5.38 with 2 Mi and 5.36 with 512 Ki; a 375 Mbp shard
+  // of a position-sharded -K 2 scan: 2.09 ms with 512 Ki, 2.31 with 1 Mi, 2.50 with 2 Mi)
   const int64_t range = end - begin;
-  if (range / ((int64_t)1 << 21) * d.ncombos >= 256 * 24) chunk = (int64_t)1 << 21;
-  else if (range / ((int64_t)1 << 20) * d.ncombos >= 256 * 8) chunk = (int64_t)1 << 20;
+  if (range / ((int64_t)1 << 21) * d.ncombos >= 256 * 16) chunk = (int64_t)1 << 21;
+  else if (range / ((int64_t)1 << 20) * d.ncombos >= 256 * 16) chunk = (int64_t)1 << 20;
   if (d.knobs.seed_chunk >= 1024 * WAVES) chunk = d.knobs.seed_chunk / (1024 * WAVES) * (1024 * WAVES);   // test knob (shared with the seed kernels)
   g.seg_len = chunk;
   const int64_t c_lo = begin / chunk, c_hi = end > begin ? (end - 1) / chunk : c_lo - 1;

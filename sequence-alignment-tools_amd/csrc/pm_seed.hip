@@ -520,6 +520,37 @@ __device__ __forceinline__ bool qgram3_close(uint32_t plo, uint32_t phi, uint32_
   return (int)(__popc(mlo & 0x5555555u) + __popc(mhi & 0x550u)) >= 18 - 3 * k;   // words 0..13 in the low dword, 14..17 at bits 28..39
 }
 
+// qgram_close && qgram3_close in one pass: the pattern XOR the stream at the 2k+1 displacements, the shifted ORs
+// behind both word lengths and the funnel of the high part are shared (the two calls one after the other computed
+// them twice: ~200 vector instructions per key match, 130 here); accumulated as AND of "some base differs" and
+// inverted once.
+__device__ __forceinline__ bool qgram_both(uint32_t plo, uint32_t phi, uint32_t tl, uint32_t th, int k) {
+  const uint32_t tm = __builtin_amdgcn_alignbit(th, tl, 24);       // stream bits 24 .. 55
+  uint32_t n4lo = ~0u, n3lo = ~0u, n4hi = ~0u, n3hi = ~0u;         // bit 2j clear: the four / three bases from j on are equal at some displacement
+  uint32_t pend = 0;
+  int npend = 0;
+  auto hi_pair = [&](uint32_t x) __attribute__((always_inline)) {
+    const uint32_t z3 = x | (x >> 2) | (x >> 4), z4 = z3 | (x >> 6);
+    n3hi &= z3 | (z3 >> 1); n4hi &= z4 | (z4 >> 1);
+  };
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) {
+    if (d < -k || d > k) continue;                                 // wave-uniform
+    const int c = 2 * (2 + d);
+    const uint32_t x = plo ^ (c ? __builtin_amdgcn_alignbit(th, tl, c) : tl);
+    const uint32_t z3 = x | (x >> 2) | (x >> 4), z4 = z3 | (x >> 6);
+    n3lo &= z3 | (z3 >> 1); n4lo &= z4 | (z4 >> 1);
+    const uint32_t y = (phi ^ (tm >> c)) & 0xffffu;
+    if (npend == 0) { pend = y; npend = 1; }
+    else { hi_pair(pend | (y << 16)); npend = 0; }
+  }
+  if (npend) hi_pair(pend | 0xffff0000u);
+  const uint32_t m4hi = ~n4hi, m3hi = ~n3hi;
+  const int c4 = __popc(~n4lo & 0x1555555u) + __popc((m4hi | (m4hi >> 16)) & 0x154u);
+  const int c3 = __popc(~n3lo & 0x5555555u) + __popc((m3hi | (m3hi >> 16)) & 0x550u);
+  return c4 >= 17 - 4 * k && c3 >= 18 - 3 * k;
+}
+
 __device__ __forceinline__ bool edits_plausible(const SeedArgs &a, int64_t p, uint32_t pi) {
   if (p - 21 < 0 || p + 3 > a.n) return true;                     // stream ends: let the automaton decide
   const uint2 pp = a.pat40[pi];                                   // base j of the last 20 at bits 2j
@@ -1002,7 +1033,10 @@ __global__ __launch_bounds__(SEED_THREADS) void pm_seed_scan(SeedArgs a) {
 // One instance per combo (pieces and displacement list are template parameters: all register indices
 // and stream offsets are immediates); the lists are edit_cover's, checked on the host at upload.
 constexpr uint32_t EDIT_MUL0 = 0x9E3779u, EDIT_MUL1 = 0xC2B2AFu, EDIT_MUL2 = 0x85EBCBu;
-constexpr int EDIT_BUCKET = 16;                                   // slots per bucket of the second stage (64 bytes, half a cache line)
+#ifndef PM_EDIT_BUCKET
+#define PM_EDIT_BUCKET 16
+#endif
+constexpr int EDIT_BUCKET = PM_EDIT_BUCKET;                       // slots per bucket of the second stage (16: 64 bytes, half a cache line)
 constexpr int EDIT_QCAP = (SEED_QCAP + SEED_Q2CAP) * 2 / 3;       // suspicious windows per wave (12-byte entries)
 __device__ __host__ __forceinline__ uint32_t edit_piece_hash(uint32_t g, uint32_t mul) {
   const uint32_t y = g * mul;                                      // g < 256, mul < 2^24: no overflow
@@ -1230,8 +1264,7 @@ __device__ __forceinline__ void edit_scan_body(const SeedArgs &a, const int comb
           at += (uint32_t)sidx;
           const uint32_t plo = __builtin_amdgcn_perm(sv >> 16, wlo, PSEL);
           const uint32_t p4 = QC == 4 ? whi : sv >> 24;
-          pass = ends || qgram_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits);
-          pass = pass && (ends || qgram3_close(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits));
+          pass = ends || qgram_both(plo, (p4 << 8) | (plo >> 24), tl, th, a.edits);
           // One report per (window, pattern) among the undisplaced tests: a pattern that agrees with the window on
           // more than three pieces is found by every triple of them; the lexicographically first triple reports
           // (every combo tests the zero displacement, and its own three pieces are among the equal ones).
@@ -1982,7 +2015,7 @@ std::string seed_build(const std::vector<Pattern> &pats, const std::vector<uint3
   const size_t bslots = tabulated ? EDIT_BUCKET : 8;
   size_t nbuckets = 256;
   // (tabulated: 200k patterns -> 32768 buckets = 2 MiB per combo; 65536 with the 1 MiB key map overflowed an XCD's 4 MiB of L2)
-  while (nbuckets * (tabulated ? 7 : 3) < np) nbuckets <<= 1;
+  while (tabulated ? nbuckets * 7 * EDIT_BUCKET < np * 16 : nbuckets * 3 < np) nbuckets <<= 1;
   int lb = 0;
   while (((size_t)1 << lb) < nbuckets) ++lb;
   t.idx_bits = idx_bits; t.bucket_shift = 32 - lb;
