@@ -394,40 +394,49 @@ def main():
         rescans[0] += 1
         pm.set_capacity(int(need * 1.25) + 1024)
 
+    # exchange buffers live across steps (allocating and zeroing them per step cost more host time than the collectives):
+    # my count, everybody's counts, my padded records, and on rank 0 one landing buffer per rank
+    xb = {"mine": None, "all": None, "pad": None, "land": None, "cap": 0}
+    if use_dist:
+        xb["mine"] = torch.zeros(1, dtype=torch.int64, device=cdev)
+        xb["all"] = torch.zeros(world, dtype=torch.int64, device=cdev)
+
     def exchange_counts(cnt, need):
         """all_gather of the ranks' record counts; a rank whose scan overflowed sends -1.  Returns the
         counts, or None when some rank has to scan again (then every rank does)."""
-        mine = torch.tensor([-1 if need else cnt], dtype=torch.int64, device=cdev)
-        clist = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
-        dist.all_gather(clist, mine)
-        cl = torch.cat(clist).tolist()                                  # one host sync for all counts
+        xb["mine"].fill_(-1 if need else cnt)
+        dist.all_gather_into_tensor(xb["all"], xb["mine"])
+        cl = xb["all"].tolist()                                         # one host sync for all counts
         if min(cl) < 0:
             if need:
                 grow(need)
             return None
         return cl
 
-    def records_for_gather(ptr, cnt, mx):
-        """this rank's records as the padded int64 buffer the gather sends: straight out of HBM with
-        RCCL; through host memory only in the gloo rehearsal (its transport is the host)"""
-        pad = torch.zeros(mx * 2, dtype=torch.int64, device=cdev)
+    def timed_gather(ptr, cnt, cl, tx0):
+        """padded gather of every rank's records to rank 0 (a record = two int64 words; every rank sends max(counts)
+        records, the receiver reads counts[r] of them): straight out of HBM with RCCL, through host memory only in the
+        gloo rehearsal (its transport is the host).  Books the exchange's host time (from tx0, the start of the count
+        exchange) and, on the nccl backend, brackets the transfer with events on the current stream."""
+        mx = max(max(cl), 1)
+        if mx > xb["cap"]:
+            xb["cap"] = mx + mx // 4 + 1024
+            xb["pad"] = torch.zeros(xb["cap"] * 2, dtype=torch.int64, device=cdev)
+            xb["land"] = [torch.zeros(xb["cap"] * 2, dtype=torch.int64, device=cdev) for _ in range(world)] if rank == 0 else None
+        cur = torch.cuda.current_stream()
+        if rank == 0 and land_stream is not None and cdev.type == "cuda":
+            cur.wait_stream(land_stream)                                # the previous step's landing still reads the buffers this gather writes
+        ev = None
+        if cdev.type == "cuda":
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        pad = xb["pad"][:mx * 2]
         if cnt:
             if cdev.type == "cuda":
                 pad[:cnt * 2].copy_(torch.as_tensor(CudaArray(ptr, cnt * 16), device=dev).view(torch.int64))
             else:
                 pad[:cnt * 2] = torch.from_numpy(pm.copy_records(ptr, cnt).view(np.int64).reshape(-1))
-        return pad
-
-    def timed_gather(ptr, cnt, cl, tx0):
-        """padded gather of every rank's records to rank 0 (a record = two int64 words); books the
-        exchange's host time (from tx0, the start of the count exchange) and, on the nccl backend,
-        brackets the transfer with events on the current stream"""
-        ev = None
-        if cdev.type == "cuda":
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        pad = records_for_gather(ptr, cnt, max(max(cl), 1))
-        gathered = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        gathered = [g[:mx * 2] for g in xb["land"]] if rank == 0 else None
         dist.gather(pad, gathered, dst=0)
         if ev:
             ev[1].record()
@@ -475,8 +484,6 @@ def main():
                     a = gathered[r][:cl[r] * 2].view(-1, 2)
                     a[:, 0] += max(0, r * shard - GUARD - HALO)        # local -> global stream index
                     all_pin[at:at + cl[r] * 2].copy_(a.reshape(-1), non_blocking=True)   # shards are in stream order
-                    if gathered[r].is_cuda:
-                        gathered[r].record_stream(land)
                     at += cl[r] * 2
             if cdev.type != "cuda":
                 torch.cuda.synchronize()

@@ -75,7 +75,7 @@ struct pm_handle {
   size_t seed_cap = 0;
   void *d_susp = nullptr;                       // pair plan: 16-byte suspect records between its scan and verify kernels
   size_t susp_cap = 0;
-  unsigned long long h_seed_count[1 + 256] = {};
+  unsigned long long *h_seed_count = nullptr;   // pinned, 1 + 256 entries: a copy into pageable memory would make the "async" scan call wait for the kernels
   std::vector<pm_hit> start_cache;    // edits: candidates that end in the first Lw+2k+2 characters (whole-prefix scans only)
   bool start_cached = false;
   uint8_t *d_dp_codes = nullptr;      // device DP (pm_cluster_dp): 32 stream codes per pattern, exact zones
@@ -227,6 +227,8 @@ static void free_device(pm_handle *h) {
   h->d_ext = nullptr; h->d_half_codes = h->d_half_len = nullptr; h->d_hesb = h->d_heeb = nullptr;
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->h_counter) (void)hipHostFree(h->h_counter);
+  if (h->h_seed_count) (void)hipHostFree(h->h_seed_count);
+  h->h_seed_count = nullptr;
   if (h->own_d_text && h->d_text) (void)hipFree((void *)h->d_text);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -627,6 +629,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   }
   if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, sizeof(unsigned long long)));
   if (!h->h_counter) HIP_TRY(h, hipHostMalloc((void **)&h->h_counter, sizeof(unsigned long long), hipHostMallocDefault));
+  if (!h->h_seed_count) { HIP_TRY(h, hipHostMalloc((void **)&h->h_seed_count, (1 + 256) * sizeof(unsigned long long), hipHostMallocDefault)); memset(h->h_seed_count, 0, (1 + 256) * sizeof(unsigned long long)); }
   if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
   if (!h->ev1) HIP_TRY(h, hipEventCreate(&h->ev1));
   if (!h->d_cands) { rc = ensure_capacity(h, (size_t)1 << 20); if (rc) return rc; }
