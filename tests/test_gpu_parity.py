@@ -100,6 +100,46 @@ def test_random_vs_oracle(seed, kernel, monkeypatch):
             assert got == want, (seed, norm, sem, k, ind, kernel, len(want), len(got))
 
 
+@pytest.mark.parametrize("row_slots", [2, 3, 5])
+def test_pair_plan_row_overflow_and_shared_keys_vs_oracle(row_slots, monkeypatch):
+    """The pair plan's slot table with tiny rows (PM_PAIR_ROW: 1, 2 or 4 slots per row of 32 keys and the overflow
+    marker): most keys lie beyond their row's slots and reach pm_pair_verify as "walk the key's pattern list" --
+    together with families of patterns that share their first or last ten bases (more than three patterns per key: the
+    slot's walk flag) and exact duplicates.  -K 1 and -K 2, every engine that builds on the candidates, tiny scan chunks:
+    the hits must be the oracle's (shift_and_inexact.cc:249-352, filter_bitvec.cc:88-177, exact_halves.cc:120-197)."""
+    monkeypatch.setenv("PM_PAIR_ROW", str(row_slots))
+    monkeypatch.setenv("PM_SEED_CHUNK", "16384")
+    monkeypatch.setenv("PM_SEED_GROUP", "3")
+    rng = np.random.default_rng(500 + row_slots)
+    ents = synth.make_entries(rng, 3, 6000, n_runs=2, repeats=True, short=True)
+    pats = synth.make_patterns(rng, ents, 900, length=20, planted=0.5)
+    # families: nine patterns with the same first ten bases, seven with the same last ten, five equal in the middle
+    s0 = ents[0]
+    a = 700
+    head, tail, mid = s0[a:a + 10].replace("N", "A"), s0[a + 40:a + 50].replace("N", "C"), s0[a + 85:a + 95].replace("N", "G")
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), size=n).tolist())
+    pats += [head + rnd(10) for _ in range(9)] + [rnd(10) + tail for _ in range(7)] + [rnd(5) + mid + rnd(5) for _ in range(5)]
+    pats += [s0[a:a + 20].replace("N", "A")] * 3 + [s0[a + 30:a + 50].replace("N", "C"), s0[a + 80:a + 100].replace("N", "G")]
+    pats += [synth.mutate(rng, s0[a:a + 20].replace("N", "A"), nsub=2), synth.mutate(rng, s0[a + 30:a + 50].replace("N", "C"), nsub=1)]
+    pats += [p + rnd(int(rng.integers(1, 12))) for p in pats[:60]]         # longer ones (the plan looks at the last 20 bases)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    for sem, osel, k in [(sat_amd.SEM_SHIFT_AND_INEXACT, 100, 2), (sat_amd.SEM_SHIFT_AND_INEXACT, 100, 1), (sat_amd.SEM_AUTO, 0, 2),
+                         (sat_amd.SEM_AUTO, 0, 1), (sat_amd.SEM_EXACT_HALVES, 12, 2)]:
+        eng = O.pick_engine(text, allp, k, False) if osel == 0 else osel
+        want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=False))
+        pm = sat_amd.PatternMatch(k=k, indels=False, semantics=sem, kernel=sat_amd.KERNEL_SEED)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        assert "pm_pair_scan" in pm.describe() and "row_slots=%d" % row_slots in pm.describe(), pm.describe()
+        got = sat_amd.sorted_tuples(pm.find_all(chunk=1 << 26))
+        pm.close()
+        assert got == want and len(want) > 30, (row_slots, sem, k, len(want), len(got))
+
+
 def test_chunked_scan_equals_whole(monkeypatch):
     """find_patterns is resumable: small pm_scan ranges give the same hit set,
     including clusters and seeds that straddle range boundaries."""
