@@ -693,10 +693,11 @@ static int ensure_packed(pm_handle *h) {
     if (h->d_packed) (void)hipFree(h->d_packed);
     h->d_packed = nullptr;
     h->packed_cap = words;
-    HIP_TRY(h, hipMalloc((void **)&h->d_packed, (words + 4) * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_packed, (words + 128) * sizeof(uint32_t)));   // + padding the scan kernels' block prefetch may read (zeroed below)
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));                      // table uploads of this init are not part of the figure
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_packed + words, 0, 128 * sizeof(uint32_t), h->stream));
   HIP_TRY(h, pack_stream(h->d_text, h->n, h->sd.ascii, h->d_packed, (int64_t)words, h->stream));
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
   HIP_TRY(h, hipEventSynchronize(h->ev1));

@@ -356,6 +356,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t q1 = ws + 1024 < own_hi ? load_packed(a.packed, a.npacked, ws + 1024 + 16 * lane) : 0u;
   uint32_t q2 = ws + 2048 < own_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
   uint32_t q3 = ws + 3072 < own_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
+  const uint32_t *pk_wave = a.packed + (ws >> 4);                 // wave-uniform: the wave's first dword (ws is a multiple of 1024)
+  uint32_t pf_idx = 4096u / 16u + (uint32_t)lane;                  // dword of this lane in the block four ahead
 
   const int negk1 = -(a.k + 1);
 
@@ -429,7 +431,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   static_assert(NR % 2 == 0 && NR >= 4 && NR <= 12, "ring size");
   uint32_t P = 0;                                                   // pending key hits: bits 0..15 previous block, 16..31 current block
   uint32_t pu1 = 0, pu2 = 0, pu3 = 0, cu1 = 0, cu2 = 0, cu3 = 0;       // stream bits 26..57 / 58..89 / 90..95 of the previous / current block's word triple
-  uint32_t prel_p = 0, prel_c = 0;                                  // position of the lane's window 0 relative to ws, previous / current block
+  uint32_t tagbase = 0xfffffff0u;                                   // 16 (block - 1): a pending window's tag = tagbase + i = 16 x its block + its index in the block
   u32x2 e_sl[NR];                                                   // slot
   uint32_t e_key[NR], e_wo[NR], e_rel[NR], e_okm[NR], e_wd[NR];       // key, other fields, position, validity (sign bit), the key's row of the bitmap
 #pragma unroll
@@ -449,7 +451,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const int d2 = __popc((x2 | (x2 >> 1)) & m5v) + negk1;
       const int d3 = __popc((x3 | (x3 >> 1)) & m5v) + (((int)e_sl[PH].y >> 28) + negk1);
       const bool susp = (int)((uint32_t)(d1 | d2 | d3) & e_okm[PH]) < 0;
-      enqueue(susp, e_key[PH], w, e_rel[PH]);
+      // (position relative to ws = 1024 x block + 16 x lane + window index, from the tag)
+      enqueue(susp, e_key[PH], w, ((e_rel[PH] >> 4) << 10) + 16u * (uint32_t)lane + (e_rel[PH] & 15u));
     }
     // stage 2: entry LD, filled last round: rank of its key inside the row -> slot (keys beyond the row's slots: its
     // last slot, the overflow marker)
@@ -466,7 +469,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       P &= P - 1u;
       const uint32_t okm = ~i;                                        // sign bit: the entry holds a window
       const bool cb = (i & 16u) != 0;                                 // window of the current block?
-      const uint32_t j2 = i << 1;                                     // (v_alignbit takes the low five bits: 2 (i & 15))
+      const uint32_t j2 = i + i;                                      // (v_alignbit takes the low five bits: 2 (i & 15); an add issues at twice a left shift's rate)
       const uint32_t u1 = cb ? cu1 : pu1, u2 = cb ? cu2 : pu2, u3 = cb ? cu3 : pu3;
       const uint32_t wlo = __builtin_amdgcn_alignbit(u2, u1, j2), whi = __builtin_amdgcn_alignbit(u3, u2, j2);   // window bits 0..31, 32..39 (+ junk above)
       // 20 bits from window bit O (O = 0, 10, 20; junk above bit 19 unless masked)
@@ -476,7 +479,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       if constexpr (D == C + 1) wo = from(10 * C) & f20v; else wo = (from(10 * C) & 0x3ffu) | (from(10 * D - 10) & 0xffc00u);
       key &= (uint32_t)((int)okm >> 31);                              // no window: key 0 (row 0: one cached line)
       e_key[PH] = key; e_wo[PH] = wo; e_okm[PH] = okm;
-      e_rel[PH] = (cb ? prel_c : prel_p) + (i & 15u);
+      e_rel[PH] = tagbase + i;
       e_wd[PH] = *lds32((key & rowmask) << 2);
     }
   };
@@ -499,7 +502,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   while (bb < own_hi) {
     const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
-    if (bb + 4096 < own_hi) q3 = load_packed(a.packed, a.npacked, bb + 4096 + 16 * lane);
+    if (bb + 4096 < own_hi) q3 = pk_wave[pf_idx];                    // (the packed stream is padded: no per-lane bounds check)
+    pf_idx += 64u;
     // the two dwords in front of every lane's own: whole-wave shifts by one lane (lane 0 takes the carry)
     const uint32_t prev1 = __builtin_amdgcn_update_dpp(carry1, cur, 0x138, 0xf, 0xf, false);       // wave_shr:1
     const uint32_t prev2 = __builtin_amdgcn_update_dpp(carry2, prev1, 0x138, 0xf, 0xf, false);     // lane 1 takes carry1 from lane 0 of prev1
@@ -528,7 +532,6 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     }
     P |= acc & (own << 16);
     cu1 = __builtin_amdgcn_alignbit(prev1, prev2, 26); cu2 = __builtin_amdgcn_alignbit(cur, prev1, 26); cu3 = cur >> 26;
-    prel_c = (uint32_t)(bb - ws) + 16 * (uint32_t)lane;
     // pass B (skipped while no lane has a hit pending and the pipeline has run empty: sparse pattern sets)
     if (__ballot(P != 0)) quiet = 0;
     if (quiet <= NR) {
@@ -536,7 +539,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       do { two_rounds(); r += 2; } while (r < rmin || __ballot((P & 0xffffu) != 0));
       quiet += r;
     }
-    P >>= 16; pu1 = cu1; pu2 = cu2; pu3 = cu3; prel_p = prel_c;
+    P >>= 16; pu1 = cu1; pu2 = cu2; pu3 = cu3; tagbase += 16u;
     bb += 1024;
   }
   while (__ballot(P != 0)) two_rounds();                            // what the last block left
