@@ -310,18 +310,12 @@ __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
   }
 }
 
-// One (field pair, chunk) of the scan.  A, B: key fields (compile time: every window offset is an
-// immediate).  See the file comment for the stages.
-//
-// Per block of 1024 positions (16 per lane) a wave runs, as straight branch-free code over the lane's
-// 16 windows:
-//   test     key -> the key's row of the LDS bitmap (1 ds_read_b32) -> bit, rank inside the row ->
-//            one 8-byte load of the key's slot from the pair's table in L2 (windows whose key is
-//            absent read a slot of row 0: one cached line, so the load needs no branch);
-//   consume  (one block later, when those loads have landed) the slot's three patterns against the
-//            window's other 20 bits: sign of min(substitutions) - (k + 1), the slot's "walk" flag folded
-//            into the third count.
-// What is left after that (1e-3 of the windows) takes the divergent path `emit`.
+// One (field pair, chunk) of the scan.  A, B: key fields (compile time: every window offset of pass A is an
+// immediate).  Per block of 1024 positions (16 per lane) a wave runs pass A -- the 16 membership tests of every
+// lane, straight-line -- and then pass B, rounds over the lanes' pending key hits (a three-stage pipeline over a
+// ring of register entries: pick the window and re-read its bitmap row; rank in the row, slot address, 8-byte
+// load; compare the slot's three patterns).  What the compare cannot dismiss (1e-3 of the windows) is queued in LDS
+// and leaves in batches for pm_pair_verify.  See the file comment and the comments at the stages.
 template <int A, int B>
 __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int combo, const int cj) {
   constexpr int C = (A != 0 && B != 0) ? 0 : ((A != 1 && B != 1) ? 1 : 2);
