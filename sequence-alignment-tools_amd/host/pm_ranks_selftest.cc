@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <vector>
 
 #include "pm_ranks.h"
@@ -12,8 +13,17 @@ using namespace pmgpu;
 
 int main(int argc, char **argv) {
   const int world = take_ranks_option(&argc, argv);
+  // --die R: rank R exits with status 3 right away and every other rank waits on something no pipe will ever end (the
+  // transfers of a device transport look like that): the launcher has to end them and report the failure
+  int die = -1;
+  for (int i = 1; i + 1 < argc; ++i) if (!strcmp(argv[i], "--die")) die = atoi(argv[i + 1]);
   RankGroup g = RankGroup::launch(world);
   const int r = g.rank();
+  if (die >= 0 && !g.single()) {
+    if (r == die) g.leave(3);
+    sleep(600);
+    g.leave(0);
+  }
   int bad = 0;
   for (int round = 0; round < 3; ++round) {
     std::vector<uint64_t> all;
