@@ -39,6 +39,9 @@ __global__ __launch_bounds__(1024) void NAME(int iters, uint32_t *out) { \
 #define AVSH(X) "%8, " X
 #define ASH17(X) "17, " X
 #define ACND(X) X ", %8, vcc"
+#define ACNDS(X) X ", %8, s[10:11]"
+#define ACMP(X) "vcc, " X ", %8"
+#define ASH64(X) "3, " X
 #define ASDWA(X) "%8, " X " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
 
 KERNEL(k_xor, I8("v_xor_b32", A2))
@@ -73,6 +76,17 @@ KERNEL(k_andor, I8("v_and_or_b32", A3))
 KERNEL(k_ashr, I8("v_ashrrev_i32", ASH))
 KERNEL(k_ffbl, I8("v_ffbl_b32", A1))
 KERNEL(k_cvt, I8("v_cvt_f32_u32", A1))
+KERNEL(k_cnd_s, I8("v_cndmask_b32_e64", ACNDS))
+KERNEL(k_mulhi, I8("v_mul_hi_u32", A2))
+KERNEL(k_sad, I8("v_sad_u32", A3))
+KERNEL(k_sadu8, I8("v_sad_u8", A3))
+KERNEL(k_bfm, I8("v_bfm_b32", A2))
+KERNEL(k_mbcnt, I8("v_mbcnt_lo_u32_b32", A2))
+KERNEL(k_alignbyte, I8("v_alignbyte_b32", A3))
+KERNEL(k_dot4, I8("v_dot4_i32_i8", A3))
+KERNEL(k_dot8, I8("v_dot8_i32_i4", A3))
+KERNEL(k_subrev, I8("v_subrev_u32", A2))
+KERNEL(k_max3, I8("v_max3_u32", A3))
 KERNEL(k_and_lit, I8("v_and_b32", ALIT))
 KERNEL(k_and_lit2, I8("v_and_b32", ALITB))
 KERNEL(k_xor_lit, I8("v_xor_b32", ALITB))
@@ -109,6 +123,7 @@ int main() {
 #define R(K) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); run(#K, K, d_out, 150 * 1024, 4);
   R(k_xor) R(k_and) R(k_add) R(k_and_s) R(k_lshr) R(k_lshrv) R(k_mov) R(k_bcnt) R(k_bfe) R(k_bfev) R(k_align) R(k_alignv) R(k_bitop3) R(k_bfi)
   R(k_min) R(k_min3) R(k_or3) R(k_add3) R(k_xad) R(k_lsa) R(k_mul24) R(k_mad24) R(k_mullo) R(k_perm) R(k_dpp) R(k_sdwa) R(k_fma) R(k_pkadd) R(k_andor)
+  R(k_cnd_s) R(k_mulhi) R(k_sad) R(k_sadu8) R(k_bfm) R(k_mbcnt) R(k_alignbyte) R(k_dot4) R(k_dot8) R(k_subrev) R(k_max3)
   R(k_ashr) R(k_ffbl) R(k_cvt) R(k_and_lit) R(k_and_lit2) R(k_xor_lit) R(k_lshr_v) R(k_lshl_v) R(k_or) R(k_sub) R(k_cnd) R(k_not) R(k_lshl17) R(k_max) R(k_addi)
   printf("-- two workgroups of 1024 per CU (8 waves per SIMD):\n");
 #define R2(K) run(#K, K, d_out, 64 * 1024, 8);
