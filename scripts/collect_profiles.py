@@ -32,7 +32,7 @@ for name in ("K2", "K0", "K1", "k1_edits", "k2_edits", "K2_1M"):
     src = one(os.path.join(G, "prof_" + tag, "kt_" + name, "*", "*kernel_stats.csv"))
     if src:
         shutil.copy(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (tag, name)))
-for name in ("tcp_gather", "pipe_overlap", "valu_rate"):               # hardware probes (scripts/probe/*.hip)
+for name in ("tcp_gather", "pipe_overlap", "valu_rate", "pack_rate"):               # hardware probes (scripts/probe/*.hip)
     src = os.path.join(G, "prof_" + tag, "probe_%s.txt" % name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, "%s_probe_%s.txt" % (tag, name)))
