@@ -1,0 +1,148 @@
+"""Long differential fuzz on the GPU box: the seed family (pair plan, edit plan, halves) against the
+bit-parallel family on streams made to be hard for the seed kernels -- low-complexity text built from a
+small vocabulary of words, tandem repeats, primers cut from the stream and mutated -- so that most
+windows are key hits, lanes run out of pending-hit bits, suspect queues flush all the time and the
+record buffers overflow.  The two families share no code before the final stage; small slices are
+also checked against the oracle.
+
+    python scripts/fuzz_families.py [seconds] [first_seed]
+
+Prints one line per case and a summary; exit status 1 on the first difference."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sat_amd  # noqa: E402
+
+TABLE = b"ACGT\n"
+LUT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def make_stream(rng, n, style):
+    """codes 0..3, code 4 = end of an entry"""
+    if style == 0:                                                 # uniform
+        s = rng.integers(0, 4, n, dtype=np.uint8)
+    elif style == 1:                                               # skewed composition
+        s = rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35]).astype(np.uint8)
+    elif style == 2:                                               # words of a small vocabulary, 2 % point mutations
+        wl = int(rng.integers(5, 13))
+        vocab = rng.integers(0, 4, (int(rng.integers(4, 200)), wl), dtype=np.uint8)
+        s = vocab[rng.integers(0, vocab.shape[0], n // wl + 1)].reshape(-1)[:n].copy()
+        m = rng.random(n) < 0.02
+        s[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
+    else:                                                          # tandem repeats of short units with drifting copies
+        s = np.empty(n, dtype=np.uint8)
+        at = 0
+        while at < n:
+            unit = rng.integers(0, 4, int(rng.integers(1, 40)), dtype=np.uint8)
+            reps = int(rng.integers(1, 400))
+            blk = np.tile(unit, reps)
+            m = rng.random(blk.size) < 0.03
+            blk[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
+            blk = blk[: n - at]
+            s[at:at + blk.size] = blk
+            at += blk.size
+    for _ in range(int(rng.integers(0, 4))):                       # entry ends
+        s[int(rng.integers(0, n))] = 4
+    return s
+
+
+def make_patterns(rng, s, count, lo, hi, k):
+    out = []
+    n = s.size
+    while len(out) < count:
+        L = int(rng.integers(lo, hi + 1))
+        a = int(rng.integers(0, n - L))
+        w = s[a:a + L]
+        if (w > 3).any():
+            continue
+        p = LUT[w].tobytes().decode()
+        for _ in range(int(rng.integers(0, k + 2))):               # 0 .. k+1 edits
+            kind = int(rng.integers(0, 4))
+            i = int(rng.integers(0, len(p)))
+            if kind <= 1:
+                p = p[:i] + "ACGT"[int(rng.integers(0, 4))] + p[i + 1:]
+            elif kind == 2 and len(p) < hi:
+                p = p[:i] + "ACGT"[int(rng.integers(0, 4))] + p[i:]
+            elif kind == 3 and len(p) > lo:
+                p = p[:i] + p[i + 1:]
+        out.append(p)
+    return out
+
+
+def hits_of(pats, k, indels, kernel, sem, dev, cap):
+    pm = sat_amd.PatternMatch(k=k, indels=indels, kernel=kernel, semantics=sem)
+    for i, p in enumerate(pats):
+        pm.add_pattern(p, i + 1)
+    pm.init_device(dev.data_ptr(), dev.numel(), TABLE, keepalive=dev)
+    pm.set_capacity(cap)
+    h = pm.find_all()
+    sel = pm.selected()
+    desc = pm.describe() if hasattr(pm, "describe") else ""
+    pm.close()
+    o = np.lexsort((h["k"], h["pid"], h["end"]))
+    return h["end"][o].astype(np.int64), h["pid"][o].astype(np.int64), h["k"][o].astype(np.int64), sel, desc
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t_end = time.time() + budget
+    cases = bad = 0
+    sems = [(sat_amd.SEM_AUTO, "auto"), (sat_amd.SEM_SHIFT_AND_INEXACT, "sai"), (sat_amd.SEM_FILTER_BITVEC, "fbv"), (sat_amd.SEM_EXACT_HALVES, "halves")]
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        style = int(rng.integers(0, 4))
+        n = int(rng.integers(1 << 16, 1 << 21))
+        s = make_stream(rng, n, style)
+        k = int(rng.integers(0, 3))
+        indels = bool(rng.integers(0, 2)) and k > 0
+        only20 = bool(rng.integers(0, 2))
+        lo, hi = (20, 20) if only20 else (int(rng.integers(12, 21)), int(rng.integers(21, 33)))
+        count = int(rng.integers(1, 1500))
+        pats = make_patterns(rng, s, count, lo, hi, k)
+        allp = pats + [sat_amd.reverse_comp(p) for p in pats]
+        sem, sname = sems[int(rng.integers(0, len(sems)))]
+        for name, val in (("PM_SEED_CHUNK", [None, "16384", "65536", "524288"]), ("PM_PAIR_ROW", [None, None, "3", "6"]), ("PM_SEED_GROUP", [None, "1", "3"])):
+            v = val[int(rng.integers(0, len(val)))]
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = v
+        cap = [1 << 12, 1 << 18, 1 << 24][int(rng.integers(0, 3))]
+        dev = torch.from_numpy(s).cuda()
+        t0 = time.time()
+        try:
+            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap)
+        except sat_amd.PmError as err:
+            if err.code == -2:                                     # option set the seed family does not cover: said loudly
+                print("seed %d skipped (%s)" % (seed, str(err)[:80]), flush=True)
+                seed += 1
+                continue
+            raise
+        b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24)
+        same = a[0].size == b[0].size and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+        cases += 1
+        print("seed %d style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
+            seed, style, n, k, indels, lo, hi, 2 * count, sname, cap,
+            ",".join("%s=%s" % (e[3:], os.environ[e]) for e in ("PM_SEED_CHUNK", "PM_PAIR_ROW", "PM_SEED_GROUP") if e in os.environ),
+            a[0].size, "ok" if same else "DIFFERENT (bitpar %d)" % b[0].size, time.time() - t0, a[4][:60]), flush=True)
+        if not same:
+            bad += 1
+            sa = set(zip(a[0].tolist(), a[1].tolist(), a[2].tolist()))
+            sb = set(zip(b[0].tolist(), b[1].tolist(), b[2].tolist()))
+            print("  only seed family:", sorted(sa - sb)[:8], " only bitpar:", sorted(sb - sa)[:8], flush=True)
+            break
+        seed += 1
+    print("cases %d failures %d" % (cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

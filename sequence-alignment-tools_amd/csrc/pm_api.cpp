@@ -1012,6 +1012,66 @@ static int stream_start_candidates(pm_handle *h) {
   return PM_OK;
 }
 
+// exact_halves reads past the end of the stream: a left half found as an exact seed right at the end is
+// extended by primer_alignment_lmatch over len2 + k characters from the seed on (primer_alignment.cc:573-574)
+// whether or not the stream still has them, and what char_io hands out there is the zero padding of the
+// mapped file's last page (mapFile.h:49-57) -- code 0, the table's first character on a normalized stream.
+// So a pattern hangs over the end by t <= len2 characters when its first L - t characters are the stream's
+// last ones (left half exact, the rest within k substitutions, none in an exact zone) and its last t
+// characters against code 0 keep the total within k: hit at end n + t.  The whole-pattern windows of the
+// seed kernels end inside the stream; these few records (flag 1: found through the left seed) are made here
+// and appended in HBM, like the records of the stream start.  With indels the half seeds are extended by
+// pm_seed_extend, which reads code 0 past the end itself.
+static int stream_end_halves_candidates(pm_handle *h) {
+  const int k = h->cfg.k;
+  const int64_t n = h->n;
+  const int64_t need = std::min<int64_t>(n, 32);
+  uint8_t tail[32] = {0};                                           // tail[32 - need .. 32) = the last `need` characters
+  if (need > 0) {
+    if (h->h_text) memcpy(tail + 32 - need, h->h_text + (n - need), (size_t)need);
+    else HIP_TRY(h, hipMemcpy(tail + 32 - need, h->d_text + (n - need), (size_t)need, hipMemcpyDeviceToHost));
+  }
+  auto differs = [&](unsigned char pc, int code) -> bool {
+    if (h->cfg.wildcards) return acgt_of(pc).find((char)h->alpha.ch[code]) == std::string::npos;
+    return code != h->alpha.nch[pc];
+  };
+  std::vector<pm_hit> extra;
+  if (h->eos_code != 0) {                                           // (code 0 = EOS: the extension's first character past the end is a violation)
+    for (size_t j = 0; j < h->pats.size(); ++j) {
+      const Pattern &p = h->pats[j];
+      const int L = (int)p.s.size(), len1 = L / 2, len2 = L - len1;
+      const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
+      for (int t = 1; t <= len2; ++t) {
+        const int inside = L - t;                                   // pattern characters 0 .. inside-1 lie on the stream's last ones
+        if (inside > need) break;
+        int lvl = 0;
+        bool dead = false;
+        for (int i = 0; i < L && !dead; ++i) {
+          const int code = i < inside ? (int)tail[32 - inside + i] : 0;
+          if (i < inside && code == h->eos_code) dead = true;
+          else if (differs((unsigned char)p.s[i], code)) {
+            if (i < len1 || i < es || i >= L - ee) dead = true;     // the seed half is exact; a substitution in an exact zone is a violation
+            else ++lvl;
+          }
+        }
+        if (!dead && lvl <= k) {
+          pm_hit x; x.end = n + t; x.pid = (uint32_t)(j + 1); x.k = (uint8_t)lvl; x.aux[0] = 1; x.aux[1] = x.aux[2] = 0;
+          extra.push_back(x);
+        }
+      }
+    }
+  }
+  if (extra.empty()) return PM_OK;
+  if (h->last_count + extra.size() > h->cap) {
+    h->overflow_need = h->last_count + extra.size();
+    h->last_count = 0;
+    return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)");
+  }
+  HIP_TRY(h, hipMemcpy(h->d_cands + h->last_count, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
+  h->last_count += extra.size();
+  return PM_OK;
+}
+
 // per pattern (index = position in the pattern list): 32 stream codes, length, exact zones -- what the
 // device-side DPs (pm_cluster_dp) and pm_bases_seeds read
 static int ensure_dp_tables(pm_handle *h) {
@@ -1122,6 +1182,11 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   if (h->kern == PM_KERNEL_SEED && h->scan_begin == 0 && h->seed_k > 0 &&
       (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT)) {
     int rc = stream_start_candidates(h);
+    if (rc) { if (rc == PM_E_OVERFLOW && n_out) *n_out = h->overflow_need; return rc; }
+    if (n_out) *n_out = h->last_count;
+  }
+  if (h->kern == PM_KERNEL_SEED && h->seed_flags && h->own_end >= h->n) {
+    int rc = stream_end_halves_candidates(h);
     if (rc) { if (rc == PM_E_OVERFLOW && n_out) *n_out = h->overflow_need; return rc; }
     if (n_out) *n_out = h->last_count;
   }

@@ -188,6 +188,48 @@ def test_edge_cases():
             assert gpu_hits(enc(s), table, [pat, pat[2:] + "AC"], sem, k, ind, kernel) == want, (k, ind, eng, kernel)
 
 
+@pytest.mark.parametrize("norm", [True, False])
+def test_extensions_read_past_the_end_of_the_stream(norm):
+    """exact_halves / exact_bases extend a seed found right at the end of the stream over characters the
+    stream no longer has: the reference reads the zero padding of the mapped file there (mapFile.h:49-57,
+    primer_alignment.cc:573-574) -- code 0, i.e. 'A' on a normalized stream, a byte no primer holds (a substitution)
+    on a raw one -- and reports hits that end up to len2 characters beyond the last one.  Found by
+    scripts/fuzz_families.py (seed 1090): the whole-pattern windows of the seed kernels end inside the stream."""
+    table = b"ACGT\n"
+    rng = np.random.default_rng(90)
+    body = "".join("ACGT"[c] for c in rng.integers(0, 4, 1500))
+    tail = "GATTACAGGCTTACCGTCAATGCCTGAAGTCCATGTTGCA"                        # the stream's last 40 characters
+    raw = ("\n" + body + tail).encode()
+    pats = []
+    for L in (14, 20, 21, 24, 32):
+        len2 = L - L // 2
+        for t in range(1, len2 + 2):                               # t = len2 + 1: the left half itself hangs over (never a hit)
+            p = tail[len(tail) - (L - t):] + "A" * t
+            pats.append(p)
+            pats.append(p[:-1] + "C")                              # one substitution in the overhang
+            if L - t - 1 >= L // 2:
+                i = L - t - 1
+                pats.append(p[:i] + "ACGT"[("ACGT".index(p[i]) + 1) % 4] + p[i + 1:])       # one in the right half on the stream
+            pats.append("ACGT"[("ACGT".index(p[0]) + 2) % 4] + p[1:])                          # one in the left half
+            if t >= 2:
+                pats.append(p[:-2] + "CG")                         # two in the overhang
+    pats = list(dict.fromkeys(pats))
+    data, tb = (synth.normalize(raw, table), table) if norm else (np.frombuffer(raw, dtype=np.uint8), None)
+    text = O.Text(data, table) if norm else O.Text(data)
+    total = 0
+    for sem, eng, k, ind in [(sat_amd.SEM_EXACT_HALVES, 12, 0, False), (sat_amd.SEM_EXACT_HALVES, 12, 1, False), (sat_amd.SEM_EXACT_HALVES, 12, 2, False),
+                             (sat_amd.SEM_EXACT_HALVES, 12, 1, True), (sat_amd.SEM_EXACT_HALVES, 12, 2, True), (sat_amd.SEM_AUTO, 0, 1, True)]:
+        use = [p for p in pats if len(p) >= 16] if ind else pats   # (exact_halves -k on the seed family: 16..32 characters)
+        e = O.pick_engine(text, use, k, ind) if eng == 0 else eng
+        want = O.sorted_tuples(O.find_all(text, use, engine=e, k=k, indels=ind))
+        beyond = [h for h in want if h[0] > len(raw)]
+        assert beyond or (not norm and k == 0), (sem, k, ind)      # (on a raw stream every character past the end is a substitution)
+        total += len(beyond)
+        for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED, sat_amd.KERNEL_AUTO):
+            assert gpu_hits(data, tb, use, sem, k, ind, kernel) == want, (norm, sem, k, ind, kernel)
+    assert total > 0
+
+
 def test_candidate_overflow_is_reported_and_recovered():
     table = b"ACGT\n"
     codes = synth.normalize(("\n" + "A" * 5000 + "\n").encode(), table)
