@@ -61,8 +61,10 @@ constexpr uint32_t WHAT_REST = 8u, WHAT_ALL = 16u;                   // suspect:
 // Slot of a key, 8 bytes: the other 20 window bits of up to three patterns that have the key
 // (o1 | o2 << 20 | o3 << 40; with fewer than three patterns the free fields repeat o1) and bit 63 =
 // "not settled by these three": more patterns share the key, or -- last slot of every row -- the key
-// lies beyond its row's slots.  Bits 60..62 are zero: the top nibble, sign-extended, is 0 or -8 and
-// goes straight into the consume stage's mismatch count.
+// lies beyond its row's slots.  It is the high dword's sign bit: the consume stage ORs that dword into its
+// three "within k" verdicts, whose sign is what it tests (bits 60..62 stay zero).  (Until round 3's fuzz the flag
+// went into the third count as -8: with -K 1 a window whose other ten bases all differ from the slot's third
+// pattern -- every window without an A, on a row's overflow marker -- came out at 10 - 8 - 2 = 0, not suspicious.)
 __device__ __host__ __forceinline__ uint64_t slot_pack(uint32_t o1, uint32_t o2, uint32_t o3, bool walk) {
   return (uint64_t)o1 | ((uint64_t)o2 << 20) | ((uint64_t)o3 << 40) | ((uint64_t)(walk ? 8 : 0) << 60);
 }
@@ -436,15 +438,15 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   auto round = [&](auto PHASE) __attribute__((always_inline)) {
     constexpr int PH = decltype(PHASE)::value, LD = (PH + NR - 1) % NR;
     // stage 3: entry PH, whose slot was loaded NR - 1 rounds ago: substitutions against each of the slot's three
-    // patterns minus k + 1; the slot's top nibble (0 or -8: "walk") is added to the third count; a negative one =
-    // suspicious (if the entry holds a window at all)
+    // patterns minus k + 1, a negative one = within k; the slot's "walk" flag is the sign bit of its high dword;
+    // any sign bit = suspicious (if the entry holds a window at all)
     {
       const uint32_t w = e_wo[PH];
       const uint32_t x1 = e_sl[PH].x ^ w, x2 = __builtin_amdgcn_alignbit(e_sl[PH].y, e_sl[PH].x, 20) ^ w, x3 = (e_sl[PH].y >> 8) ^ w;
       const int d1 = __popc((x1 | (x1 >> 1)) & m5v) + negk1;
       const int d2 = __popc((x2 | (x2 >> 1)) & m5v) + negk1;
-      const int d3 = __popc((x3 | (x3 >> 1)) & m5v) + (((int)e_sl[PH].y >> 28) + negk1);
-      const bool susp = (int)((uint32_t)(d1 | d2 | d3) & e_okm[PH]) < 0;
+      const int d3 = __popc((x3 | (x3 >> 1)) & m5v) + negk1;
+      const bool susp = (int)(((uint32_t)(d1 | d2 | d3) | e_sl[PH].y) & e_okm[PH]) < 0;
       // (position relative to ws = 1024 x block + 16 x lane + window index, from the tag)
       enqueue(susp, e_key[PH], w, ((e_rel[PH] >> 4) << 10) + 16u * (uint32_t)lane + (e_rel[PH] & 15u));
     }

@@ -140,6 +140,59 @@ def test_pair_plan_row_overflow_and_shared_keys_vs_oracle(row_slots, monkeypatch
         assert got == want and len(want) > 30, (row_slots, sem, k, len(want), len(got))
 
 
+@pytest.mark.parametrize("row_slots", [None, 2, 3])
+def test_pair_plan_flagged_slots_with_nothing_in_common(row_slots, monkeypatch):
+    """What the consume stage of pm_pair_scan must not dismiss although none of a slot's three patterns is near the
+    window: keys beyond their row's slots (the row's overflow marker holds no pattern: its fields read AAAAAAAAAA, and
+    a window without an A differs from that in all ten bases) and keys with more than three patterns whose fourth
+    differs from the third everywhere.  For every field pair: six row mates (same key fields but for the key's last two
+    bases) with A-free other fields, and five patterns on one key, the other fields of the fourth and fifth chosen
+    against the third's.  scripts/fuzz_families.py seed 1175 found the -K 1 case (the flag used to enter the third
+    count as -8: 10 - 8 - 2 = 0 was "not suspicious").  Oracle: shift_and_inexact.cc:249-352, exact_halves.cc:120-197."""
+    if row_slots is not None:
+        monkeypatch.setenv("PM_PAIR_ROW", str(row_slots))
+    monkeypatch.setenv("PM_SEED_CHUNK", "16384")
+    rng = np.random.default_rng(1175)
+    rnd = lambda n, al="ACGT": "".join(rng.choice(list(al), size=n).tolist())
+    shift = lambda w, j: "".join("ACGT"[("ACGT".index(c) + j) % 4] for c in w)
+    pats = []
+    for fa in range(4):
+        for fb in range(fa + 1, 4):
+            others = [f for f in range(4) if f not in (fa, fb)]
+            def build(ka, kb, o1, o2):
+                fields = [None] * 4
+                fields[fa], fields[fb], fields[others[0]], fields[others[1]] = ka, kb, o1, o2
+                return "".join(fields)
+            ka, kb3 = rnd(5), rnd(3)
+            for tail2 in ("AA", "AC", "CG", "GT", "TA", "TT"):       # row mates: the key's bit index differs, its row does not
+                pats.append(build(ka, kb3 + tail2, rnd(5, "CGT"), rnd(5, "CGT")))
+            ka, kb = rnd(5), rnd(5)                                   # five patterns on one key
+            o = rnd(10)
+            for w in (o, rnd(10), shift(o, 1), shift(o, 2), shift(o, 3)):   # the 4th and 5th differ from the 3rd in all ten bases
+                pats.append(build(ka, kb, w[:5], w[5:]))
+    pats += [rnd(int(rng.integers(1, 8))) + p for p in pats[:20]]     # longer ones (the plan looks at the last 20 bases)
+    sites = []
+    for p in pats:
+        sites += [p, synth.mutate(rng, p, nsub=1), synth.mutate(rng, p, nsub=2), synth.mutate(rng, p, nsub=3)]
+    order = rng.permutation(len(sites))
+    raw = ("\n" + "".join(rnd(int(rng.integers(3, 60))) + sites[i] for i in order) + rnd(50) + "\n").encode()
+    table = b"ACGT\n"
+    codes = synth.normalize(raw, table)
+    text = O.Text(codes, table)
+    allp = pats + [synth.revcomp(p) for p in pats]
+    for sem, eng, k in [(sat_amd.SEM_SHIFT_AND_INEXACT, 100, 1), (sat_amd.SEM_SHIFT_AND_INEXACT, 100, 2), (sat_amd.SEM_FILTER_BITVEC, 5, 1),
+                        (sat_amd.SEM_EXACT_HALVES, 12, 1), (sat_amd.SEM_EXACT_HALVES, 12, 2)]:
+        want = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=False))
+        pm = sat_amd.PatternMatch(k=k, indels=False, semantics=sem, kernel=sat_amd.KERNEL_SEED)
+        for i, p in enumerate(allp):
+            pm.add_pattern(p, i + 1)
+        pm.init(codes, table)
+        assert "pm_pair_scan" in pm.describe() and (row_slots is None or "row_slots=%d" % row_slots in pm.describe()), pm.describe()
+        got = sat_amd.sorted_tuples(pm.find_all(chunk=1 << 26))
+        pm.close()
+        assert got == want and len(want) >= len(pats), (row_slots, sem, k, len(want), len(got), sorted(set(want) - set(got))[:5])
+
+
 def test_chunked_scan_equals_whole(monkeypatch):
     """find_patterns is resumable: small pm_scan ranges give the same hit set,
     including clusters and seeds that straddle range boundaries."""
