@@ -78,6 +78,8 @@ struct pm_handle {
   unsigned long long *h_seed_count = nullptr;   // pinned, 1 + 256 entries: a copy into pageable memory would make the "async" scan call wait for the kernels
   std::vector<pm_hit> start_cache;    // edits: candidates that end in the first Lw+2k+2 characters (whole-prefix scans only)
   bool start_cached = false;
+  std::vector<pm_hit> end_cache;      // edits: candidates that end in the last four characters (scans that reach the end of the stream)
+  bool end_cached = false;
   uint8_t *d_dp_codes = nullptr;      // device DP (pm_cluster_dp): 32 stream codes per pattern, exact zones
   int32_t *d_dp_esb = nullptr, *d_dp_eeb = nullptr;
   pm_hit *d_ext = nullptr;            // its output (swapped with d_cands after every scan)
@@ -437,7 +439,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->seed_flags = false; h->bases_flags = false; h->bases_edits = false; h->half_ranked_any = false;
   h->zoned = false;
   for (const Pattern &p : h->pats) h->zoned = h->zoned || p.esb || p.eeb;
-  h->start_cached = false; h->start_cache.clear();
+  h->start_cached = false; h->start_cache.clear(); h->end_cached = false; h->end_cache.clear();
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
   // A pattern set is rarely uniform: a few primers with an ambiguity letter, one that is too short
@@ -968,6 +970,60 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
   return PM_OK;
 }
 
+// Edit-distance seed plan, the other end: a match whose clean pieces are followed by deleted pattern characters is
+// seeded by the window one or two positions BEHIND its end (the seed's place is where the pattern's last base
+// would be), and behind the last character of the stream there are no windows.  The candidates that end in the
+// last four characters are therefore produced here as well: the automaton from the empty state over the last
+// L + k + 8 characters -- its last bit depends on the last L + k only -- (from the stream-start state when that
+// is the whole stream); duplicates of the kernel's records leave with the dedup.  Computed once per stream.
+// Found by scripts/fuzz_families.py (seed 1308).
+static int edits_end_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
+  const int k = h->cfg.k;
+  const int64_t n = h->n;
+  if (h->scan_end < n || n <= 0) return PM_OK;
+  if (h->end_cached) {
+    for (const pm_hit &x : h->end_cache) if (x.end > h->scan_begin) extra->push_back(x);
+    return PM_OK;
+  }
+  const int64_t T = std::min<int64_t>(n, 32 + k + 8);
+  uint8_t tail[64] = {0};
+  if (h->h_text) memcpy(tail, h->h_text + (n - T), (size_t)T);
+  else HIP_TRY(h, hipMemcpy(tail, h->d_text + (n - T), (size_t)T, hipMemcpyDeviceToHost));
+  std::vector<pm_hit> all;
+  for (size_t j = 0; j < h->inner.size(); ++j) {
+    if (j < h->in_rest.size() && h->in_rest[j]) continue;           // the residue engine reports its own
+    const std::string &s = h->inner[j].s;
+    const int L = (int)s.size();
+    const int64_t Tj = std::min<int64_t>(T, L + k + 8);
+    uint64_t R[3] = {0, 0, 0};
+    if (Tj == n) { R[1] = 1; R[2] = 3; }                            // the whole stream: rows start with l prefix bits
+    const uint64_t last = 1ull << (L - 1);
+    uint64_t M[4] = {0, 0, 0, 0};
+    int code[4];
+    for (int q = 0; q < 4; ++q) code[q] = h->alpha.nch[(unsigned char)"ACGT"[q]];
+    for (int i = 0; i < L; ++i) for (int q = 0; q < 4; ++q)
+      if (h->wild_seed ? acgt_of((unsigned char)s[i]).find("ACGT"[q]) != std::string::npos : s[i] == "ACGT"[q]) M[q] |= 1ull << i;
+    for (int64_t t = T - Tj; t < T; ++t) {
+      const int c = tail[t];
+      if (c == h->eos_code) { R[0] = R[1] = R[2] = 0; continue; }
+      const uint64_t U = c == code[0] ? M[0] : c == code[1] ? M[1] : c == code[2] ? M[2] : c == code[3] ? M[3] : 0;
+      const uint64_t x0 = (R[0] << 1) | 1, m1 = x0 | R[0], n0 = x0 & U;
+      const uint64_t x1 = (R[1] << 1) | 1, n1 = (x1 & U) | m1 | (n0 << 1) | 1 | n0, m2 = x1 | R[1];
+      const uint64_t x2 = (R[2] << 1) | 1, n2 = (x2 & U) | m2 | (n1 << 1) | 1 | n1;
+      R[0] = n0; R[1] = n1; R[2] = n2;
+      const int lvl = (R[0] & last) ? 0 : (R[1] & last) ? 1 : (k >= 2 && (R[2] & last)) ? 2 : -1;
+      const int64_t end = n - T + t + 1;
+      if (lvl >= 0 && end > n - 4) {
+        pm_hit x; x.end = end; x.pid = h->inner_ids[j]; x.k = (uint8_t)lvl; x.aux[0] = x.aux[1] = x.aux[2] = 0;
+        all.push_back(x);
+      }
+    }
+  }
+  h->end_cache = all; h->end_cached = true;
+  for (const pm_hit &x : all) if (x.end > h->scan_begin) extra->push_back(x);
+  return PM_OK;
+}
+
 // The k-error automaton starts with the first l bits of every pattern set in row l
 // (shift_and_inexact.cc:162-164), so at the very start of the stream a pattern whose first
 // d <= k characters are "missing" is reported at end = L-d with level d + mismatches.  The seed
@@ -1159,9 +1215,11 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   if (h->edits_dev) {
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
-    if (h->scan_begin == 0 && !h->bases_edits) {                    // (exact_bases: the records are block seeds, not automaton ends)
+    if ((h->scan_begin == 0 || h->scan_end >= h->n) && !h->bases_edits) {   // (exact_bases: the records are block seeds, not automaton ends)
       std::vector<pm_hit> extra;
-      int rc = edits_start_candidates(h, &extra);
+      int rc = h->scan_begin == 0 ? edits_start_candidates(h, &extra) : PM_OK;
+      if (rc) return rc;
+      rc = edits_end_candidates(h, &extra);
       if (rc) return rc;
       if (tot + extra.size() > h->cap) { h->last_count = 0; if (n_out) *n_out = tot + extra.size(); return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
       if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));

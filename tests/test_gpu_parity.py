@@ -283,6 +283,42 @@ def test_extensions_read_past_the_end_of_the_stream(norm):
     assert total > 0
 
 
+def test_edit_plan_matches_that_end_with_the_stream():
+    """-k on the seed family at the very end of the stream: a match whose last characters need a pattern character
+    deleted is seeded by the window one or two positions behind its end, where the stream has no windows
+    (scripts/fuzz_families.py seed 1308).  Patterns = the stream's last 18..31 characters with one or two characters
+    inserted / substituted / removed at every place near their end; with and without an entry end in front.
+    Oracle: shift_and_inexact.cc:249-352, filter_bitvec.cc:88-177."""
+    table = b"ACGT\n"
+    rng = np.random.default_rng(1308)
+    rnd = lambda n: "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    for tail_eos in (False, True):
+        raw = ("\n" + rnd(4000) + ("\n" if tail_eos else "")).encode()
+        core = raw[:-1] if tail_eos else raw
+        pats = []
+        for L in (18, 19, 20, 21, 25, 31):
+            site = core[-L:].decode()
+            for i in range(L - 8, L + 1):
+                for c in "ACGT":
+                    pats.append(site[:i] + c + site[i:])                           # one character the stream does not have
+                    for i2 in range(i, L + 1):
+                        pats.append(site[:i] + c + site[i:i2] + "G" + site[i2:])   # two of them
+                    if i < L:
+                        pats.append(site[:i] + c + site[i + 1:])                   # substitution
+                        pats.append(site[:i] + site[i + 1:])                       # the stream has one more
+        pats = [p for p in dict.fromkeys(pats) if 20 <= len(p) <= 32]
+        codes = synth.normalize(raw, table)
+        text = O.Text(codes, table)
+        for sem, eng, k in [(sat_amd.SEM_FILTER_BITVEC, 5, 2), (sat_amd.SEM_FILTER_BITVEC, 5, 1), (sat_amd.SEM_SHIFT_AND_INEXACT, 100, 2),
+                            (sat_amd.SEM_SHIFT_AND_INEXACT, 100, 1), (sat_amd.SEM_EXACT_HALVES, 12, 2)]:
+            want = O.sorted_tuples(O.find_all(text, pats, engine=eng, k=k, indels=True))
+            at_end = [h for h in want if h[0] >= len(core) - 1]
+            assert len(at_end) > 50, (sem, k, len(at_end))
+            for kernel in (sat_amd.KERNEL_SEED, sat_amd.KERNEL_BITPAR):
+                got = gpu_hits(codes, table, pats, sem, k, True, kernel)
+                assert got == want, (tail_eos, sem, k, kernel, len(want), len(got), sorted(set(want) - set(got))[:5])
+
+
 def test_candidate_overflow_is_reported_and_recovered():
     table = b"ACGT\n"
     codes = synth.normalize(("\n" + "A" * 5000 + "\n").encode(), table)
