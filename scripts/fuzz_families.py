@@ -76,18 +76,45 @@ def make_patterns(rng, s, count, lo, hi, k):
     return out
 
 
-def hits_of(pats, k, indels, kernel, sem, dev, cap):
+def sort3(end, pid, k):
+    o = np.lexsort((k, pid, end))
+    return end[o].astype(np.int64), pid[o].astype(np.int64), k[o].astype(np.int64)
+
+
+def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABLE):
+    """mode 0: find_all over the whole stream; 1: find_all in small chunks (resumable scans); 2: one scan + the
+    device finalize (bench.py's single-rank path); 3: two position shards, each finalized on its own with a guard
+    band (bench.py's multi-rank path).  Raises PmError(-2) where the library says the mode does not apply."""
     pm = sat_amd.PatternMatch(k=k, indels=indels, kernel=kernel, semantics=sem)
     for i, p in enumerate(pats):
         pm.add_pattern(p, i + 1)
-    pm.init_device(dev.data_ptr(), dev.numel(), TABLE, keepalive=dev)
+    pm.init_device(dev.data_ptr(), dev.numel(), table, keepalive=dev)
     pm.set_capacity(cap)
-    h = pm.find_all()
-    sel = pm.selected()
-    desc = pm.describe() if hasattr(pm, "describe") else ""
-    pm.close()
-    o = np.lexsort((h["k"], h["pid"], h["end"]))
-    return h["end"][o].astype(np.int64), h["pid"][o].astype(np.int64), h["k"][o].astype(np.int64), sel, desc
+    n = dev.numel()
+    try:
+        if mode == 0:
+            h = pm.find_all()
+        elif mode == 1:
+            h = pm.find_all(chunk=int(rng.integers(2000, 300000)))
+        elif mode == 2:
+            pm.reset()
+            pm.scan_candidates(0, n, to_host=False)
+            h = pm.finalize_device(n, last=True, sort=True)
+        else:
+            guard = 4096
+            cut = int(rng.integers(n // 4, 3 * n // 4))
+            parts = []
+            for own_lo, own_hi in ((0, cut), (cut, n)):
+                g_lo, g_hi = max(0, own_lo - guard), min(n, own_hi + guard)
+                pm.reset()
+                pm.scan_candidates(g_lo, g_hi, to_host=False)
+                parts.append(pm.finalize_device(0, sort=True, owned=(own_lo, own_hi, g_lo, None if g_hi == n else g_hi)).copy())
+            h = np.concatenate(parts)
+        sel = pm.selected()
+        desc = pm.describe()
+    finally:
+        pm.close()
+    return sort3(h["end"], h["pid"], h["k"]) + (sel, desc)
 
 
 def main():
@@ -116,21 +143,24 @@ def main():
             else:
                 os.environ[name] = v
         cap = [1 << 12, 1 << 18, 1 << 24][int(rng.integers(0, 3))]
-        dev = torch.from_numpy(s).cuda()
+        mode = int(rng.integers(0, 4))
+        raw = bool(rng.integers(0, 4) == 0)                            # the stream as bytes 'A','C','G','T','\n' with no table
+        table = None if raw else TABLE
+        dev = torch.from_numpy(np.frombuffer(b"ACGT\n", dtype=np.uint8)[s] if raw else s).cuda()
         t0 = time.time()
         try:
-            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap)
+            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap, mode, rng, table)
         except sat_amd.PmError as err:
-            if err.code == -2:                                     # option set the seed family does not cover: said loudly
-                print("seed %d skipped (%s)" % (seed, str(err)[:80]), flush=True)
+            if err.code == -2 or "chain" in str(err):                  # option set / mode the library does not cover: said loudly
+                print("seed %d mode %d skipped (%s)" % (seed, mode, str(err)[:100]), flush=True)
                 seed += 1
                 continue
             raise
-        b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24)
+        b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24, 0, rng, table)
         same = a[0].size == b[0].size and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
         cases += 1
-        print("seed %d style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
-            seed, style, n, k, indels, lo, hi, 2 * count, sname, cap,
+        print("seed %d mode %d%s style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
+            seed, mode, " raw" if raw else "", style, n, k, indels, lo, hi, 2 * count, sname, cap,
             ",".join("%s=%s" % (e[3:], os.environ[e]) for e in ("PM_SEED_CHUNK", "PM_PAIR_ROW", "PM_SEED_GROUP") if e in os.environ),
             a[0].size, "ok" if same else "DIFFERENT (bitpar %d)" % b[0].size, time.time() - t0, a[4][:60]), flush=True)
         if not same:
