@@ -81,13 +81,16 @@ def sort3(end, pid, k):
     return end[o].astype(np.int64), pid[o].astype(np.int64), k[o].astype(np.int64)
 
 
-def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABLE):
+def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABLE, zones=None, wild=False):
     """mode 0: find_all over the whole stream; 1: find_all in small chunks (resumable scans); 2: one scan + the
     device finalize (bench.py's single-rank path); 3: two position shards, each finalized on its own with a guard
     band (bench.py's multi-rank path).  Raises PmError(-2) where the library says the mode does not apply."""
-    pm = sat_amd.PatternMatch(k=k, indels=indels, kernel=kernel, semantics=sem)
+    pm = sat_amd.PatternMatch(k=k, indels=indels, kernel=kernel, semantics=sem, wildcards=wild)
     for i, p in enumerate(pats):
-        pm.add_pattern(p, i + 1)
+        if zones is None:
+            pm.add_pattern(p, i + 1)
+        else:
+            pm.add_pattern(p, i + 1, zones[i][0], zones[i][1])
     pm.init_device(dev.data_ptr(), dev.numel(), table, keepalive=dev)
     pm.set_capacity(cap)
     n = dev.numel()
@@ -122,7 +125,9 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t_end = time.time() + budget
     cases = bad = 0
-    sems = [(sat_amd.SEM_AUTO, "auto"), (sat_amd.SEM_SHIFT_AND_INEXACT, "sai"), (sat_amd.SEM_FILTER_BITVEC, "fbv"), (sat_amd.SEM_EXACT_HALVES, "halves")]
+    sems = [(sat_amd.SEM_AUTO, "auto"), (sat_amd.SEM_SHIFT_AND_INEXACT, "sai"), (sat_amd.SEM_FILTER_BITVEC, "fbv"), (sat_amd.SEM_EXACT_HALVES, "halves"),
+            (sat_amd.SEM_EXACT_BASES, "bases")]
+    IUPAC = {"A": "RWMDHVN", "C": "YSMBHVN", "G": "RSKBDVN", "T": "YWKBDHN"}
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
         style = int(rng.integers(0, 4))
@@ -136,7 +141,33 @@ def main():
         pats = make_patterns(rng, s, count, lo, hi, k)
         allp = pats + [sat_amd.reverse_comp(p) for p in pats]
         sem, sname = sems[int(rng.integers(0, len(sems)))]
-        for name, val in (("PM_SEED_CHUNK", [None, "16384", "65536", "524288"]), ("PM_PAIR_ROW", [None, None, "3", "6"]), ("PM_SEED_GROUP", [None, "1", "3"])):
+        # exact zones (exact_start_bases / exact_end_bases) on a third of the cases, always for exact_bases
+        zones = None
+        if sem == sat_amd.SEM_EXACT_BASES or rng.integers(0, 3) == 0:
+            zones = []
+            for p in allp:
+                e, f_ = (int(rng.integers(0, 9)), 0) if rng.integers(0, 2) else (0, int(rng.integers(0, 9)))
+                if rng.integers(0, 4) == 0:
+                    e, f_ = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+                if sem == sat_amd.SEM_EXACT_BASES and max(e, f_) < 6:
+                    e = 6 + int(rng.integers(0, 4))
+                zones.append((min(e, len(p)), min(f_, len(p))))
+        # ambiguity codes in the primers (-w) on a sixth of the cases
+        wild = bool(rng.integers(0, 6) == 0)
+        if wild:
+            wp = []
+            for p in allp:
+                q = list(p)
+                for _ in range(int(rng.integers(0, 3))):
+                    i = int(rng.integers(0, len(q)))
+                    if q[i] in IUPAC:
+                        q[i] = IUPAC[q[i]][int(rng.integers(0, 7))]
+                wp.append("".join(q))
+            allp = wp
+        # a few characters that are no base (N) in the stream on a quarter of the cases
+        with_n = bool(rng.integers(0, 4) == 0)
+        for name, val in (("PM_SEED_CHUNK", [None, "16384", "65536", "524288"]), ("PM_PAIR_ROW", [None, None, "3", "6"]), ("PM_SEED_GROUP", [None, "1", "3"]),
+                          ("PM_SEED_TILE", [None, None, "300", "1000"])):
             v = val[int(rng.integers(0, len(val)))]
             if v is None:
                 os.environ.pop(name, None)
@@ -145,23 +176,31 @@ def main():
         cap = [1 << 12, 1 << 18, 1 << 24][int(rng.integers(0, 3))]
         mode = int(rng.integers(0, 4))
         raw = bool(rng.integers(0, 4) == 0)                            # the stream as bytes 'A','C','G','T','\n' with no table
-        table = None if raw else TABLE
-        dev = torch.from_numpy(np.frombuffer(b"ACGT\n", dtype=np.uint8)[s] if raw else s).cuda()
+        table = None if raw else (b"ACGT\nN" if with_n else TABLE)
+        if with_n:
+            s = s.copy()
+            s[rng.integers(0, n, int(rng.integers(1, 200)))] = 5
+        dev = torch.from_numpy(np.frombuffer(b"ACGT\nN", dtype=np.uint8)[s] if raw else s).cuda()
         t0 = time.time()
         try:
-            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap, mode, rng, table)
+            b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24, 0, rng, table, zones, wild)
+        except sat_amd.PmError as err:                                 # an option set the reference rejects as well (e.g. k too large for the zones)
+            print("seed %d skipped: the bit-parallel family says %s" % (seed, str(err)[:100]), flush=True)
+            seed += 1
+            continue
+        try:
+            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap, mode, rng, table, zones, wild)
         except sat_amd.PmError as err:
             if err.code == -2 or "chain" in str(err):                  # option set / mode the library does not cover: said loudly
                 print("seed %d mode %d skipped (%s)" % (seed, mode, str(err)[:100]), flush=True)
                 seed += 1
                 continue
             raise
-        b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24, 0, rng, table)
         same = a[0].size == b[0].size and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
         cases += 1
-        print("seed %d mode %d%s style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
-            seed, mode, " raw" if raw else "", style, n, k, indels, lo, hi, 2 * count, sname, cap,
-            ",".join("%s=%s" % (e[3:], os.environ[e]) for e in ("PM_SEED_CHUNK", "PM_PAIR_ROW", "PM_SEED_GROUP") if e in os.environ),
+        print("seed %d mode %d%s%s%s%s style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
+            seed, mode, " raw" if raw else "", " zones" if zones else "", " wild" if wild else "", " N" if with_n else "", style, n, k, indels, lo, hi, 2 * count, sname, cap,
+            ",".join("%s=%s" % (e[3:], os.environ[e]) for e in ("PM_SEED_CHUNK", "PM_PAIR_ROW", "PM_SEED_GROUP", "PM_SEED_TILE") if e in os.environ),
             a[0].size, "ok" if same else "DIFFERENT (bitpar %d)" % b[0].size, time.time() - t0, a[4][:60]), flush=True)
         if not same:
             bad += 1

@@ -501,6 +501,10 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     } else if (h->nrest) {
       for (size_t i = 0; i < h->inner.size(); ++i) if (!h->in_rest[i]) { sp.push_back(h->inner[i]); sid.push_back(h->inner_ids[i]); }
     } else { sp = h->inner; sid = h->inner_ids; }
+    // the automata and the keyword tree know nothing of exact_start_bases / exact_end_bases (shift_and_inexact.cc:85-86
+    // stores them and never looks): their records are every window within k, whatever zone a substitution falls in
+    if (h->sem == PM_SEM_SHIFT_AND_INEXACT || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_KEYWORD_TREE)
+      for (Pattern &p : sp) { p.esb = 0; p.eeb = 0; }
     // One LDS Bloom filter (1 Mbit) stays selective up to ~256k keys: larger pattern sets are cut
     // into tiles with their own tables; the scan launches once per tile into the same record buffer.
     size_t tile_keys = 262144;
@@ -1077,8 +1081,9 @@ static int stream_start_candidates(pm_handle *h) {
 // characters against code 0 keep the total within k: hit at end n + t.  The whole-pattern windows of the
 // seed kernels end inside the stream; these few records (flag 1: found through the left seed) are made here
 // and appended in HBM, like the records of the stream start.  With indels the half seeds are extended by
-// pm_seed_extend, which reads code 0 past the end itself.
-static int stream_end_halves_candidates(pm_handle *h) {
+// pm_seed_extend, which reads code 0 past the end itself.  exact_bases -K is the same with the mandated first
+// block in the left half's place (its records are final: the primer's id, no flag).
+static int stream_end_overhang_candidates(pm_handle *h, bool bases) {
   const int k = h->cfg.k;
   const int64_t n = h->n;
   const int64_t need = std::min<int64_t>(n, 32);
@@ -1095,8 +1100,12 @@ static int stream_end_halves_candidates(pm_handle *h) {
   if (h->eos_code != 0) {                                           // (code 0 = EOS: the extension's first character past the end is a violation)
     for (size_t j = 0; j < h->pats.size(); ++j) {
       const Pattern &p = h->pats[j];
-      const int L = (int)p.s.size(), len1 = L / 2, len2 = L - len1;
+      const int L = (int)p.s.size();
       const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
+      // the part found as an exact seed inside the stream: the left half (exact_halves), the mandated first block
+      // (exact_bases with esb >= eeb, exact_bases.cc:139-150; a last block lies on the stream with all of its pattern)
+      if (bases && (es < ee || es == 0)) continue;
+      const int len1 = bases ? es : L / 2, len2 = L - len1;
       for (int t = 1; t <= len2; ++t) {
         const int inside = L - t;                                   // pattern characters 0 .. inside-1 lie on the stream's last ones
         if (inside > need) break;
@@ -1111,7 +1120,7 @@ static int stream_end_halves_candidates(pm_handle *h) {
           }
         }
         if (!dead && lvl <= k) {
-          pm_hit x; x.end = n + t; x.pid = (uint32_t)(j + 1); x.k = (uint8_t)lvl; x.aux[0] = 1; x.aux[1] = x.aux[2] = 0;
+          pm_hit x; x.end = n + t; x.pid = bases ? (uint32_t)p.id : (uint32_t)(j + 1); x.k = (uint8_t)lvl; x.aux[0] = bases ? 0 : 1; x.aux[1] = x.aux[2] = 0;
           extra.push_back(x);
         }
       }
@@ -1215,6 +1224,39 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   if (h->edits_dev) {
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
+    if (h->bases_edits && h->scan_end >= h->n) {
+      // exact_bases -k: the records are occurrences of the mandated block, found through windows within k edits of
+      // the whole pattern -- which a pattern that hangs over the end of the stream does not have (the extension DP
+      // reads code 0 there, see stream_end_overhang_candidates).  The occurrences of a first block close enough to
+      // the end for that come from the host; duplicates leave with the dedup.
+      std::vector<pm_hit> extra;
+      const int64_t n = h->n;
+      const int64_t need = std::min<int64_t>(n, 32 + 2 * h->cfg.k + 2);
+      uint8_t tail[64] = {0};
+      if (need > 0) {
+        if (h->h_text) memcpy(tail, h->h_text + (n - need), (size_t)need);
+        else HIP_TRY(h, hipMemcpy(tail, h->d_text + (n - need), (size_t)need, hipMemcpyDeviceToHost));
+      }
+      for (size_t j = 0; j < h->pats.size(); ++j) {
+        const Pattern &p = h->pats[j];
+        const int L = (int)p.s.size();
+        const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
+        if (es < ee || es == 0) continue;
+        for (int64_t b0 = std::max<int64_t>(n - need, n - L - 2 * h->cfg.k - 2); b0 + es <= n; ++b0) {
+          if (b0 < 0) continue;
+          bool ok = true;
+          for (int q = 0; q < es && ok; ++q) ok = (int)tail[need - (n - b0) + q] == h->alpha.nch[(unsigned char)p.s[q]];
+          const int64_t send = b0 + es;
+          if (ok && send > h->own_begin && send <= h->own_end) {
+            pm_hit x; x.end = send; x.pid = (uint32_t)(j + 1); x.k = 0; x.aux[0] = x.aux[1] = x.aux[2] = 0;
+            extra.push_back(x);
+          }
+        }
+      }
+      if (tot + extra.size() > h->cap) { h->last_count = 0; if (n_out) *n_out = tot + extra.size(); return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
+      if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
+      tot += extra.size();
+    }
     if ((h->scan_begin == 0 || h->scan_end >= h->n) && !h->bases_edits) {   // (exact_bases: the records are block seeds, not automaton ends)
       std::vector<pm_hit> extra;
       int rc = h->scan_begin == 0 ? edits_start_candidates(h, &extra) : PM_OK;
@@ -1243,8 +1285,8 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
     if (rc) { if (rc == PM_E_OVERFLOW && n_out) *n_out = h->overflow_need; return rc; }
     if (n_out) *n_out = h->last_count;
   }
-  if (h->kern == PM_KERNEL_SEED && h->seed_flags && h->own_end >= h->n) {
-    int rc = stream_end_halves_candidates(h);
+  if (h->kern == PM_KERNEL_SEED && (h->seed_flags || h->bases_flags) && h->own_end >= h->n) {
+    int rc = stream_end_overhang_candidates(h, h->bases_flags);
     if (rc) { if (rc == PM_E_OVERFLOW && n_out) *n_out = h->overflow_need; return rc; }
     if (n_out) *n_out = h->last_count;
   }

@@ -281,6 +281,18 @@ def test_extensions_read_past_the_end_of_the_stream(norm):
         for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED, sat_amd.KERNEL_AUTO):
             assert gpu_hits(data, tb, use, sem, k, ind, kernel) == want, (norm, sem, k, ind, kernel)
     assert total > 0
+    # exact_bases: the mandated first block found right at the end, the remainder extended past it
+    # (exact_bases.cc:92-121); a mandated last block keeps the whole pattern on the stream
+    use = [p for p in pats if len(p) >= 20]
+    for esb, eeb in [(8, 0), (6, 3), (0, 7)]:
+        E, F = [esb] * len(use), [eeb] * len(use)
+        for k, ind in [(1, False), (2, False), (1, True), (2, True)]:
+            want = O.sorted_tuples(O.find_all(text, use, engine=8, k=k, indels=ind, esb=E, eeb=F))
+            beyond = [h for h in want if h[0] > len(raw)]
+            assert bool(beyond) == (esb >= eeb) or not norm, (esb, eeb, k, ind, len(beyond))
+            for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED):
+                got = gpu_hits(data, tb, use, sat_amd.SEM_EXACT_BASES, k, ind, kernel, esb=E, eeb=F)
+                assert got == want, (norm, esb, eeb, k, ind, kernel, len(want), len(got), sorted(set(want) - set(got))[:4])
 
 
 def test_edit_plan_matches_that_end_with_the_stream():
