@@ -1224,32 +1224,43 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   if (h->edits_dev) {
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
-    if (h->bases_edits && h->scan_end >= h->n) {
+    if (h->bases_edits && (h->scan_begin == 0 || h->scan_end >= h->n)) {
       // exact_bases -k: the records are occurrences of the mandated block, found through windows within k edits of
-      // the whole pattern -- which a pattern that hangs over the end of the stream does not have (the extension DP
-      // reads code 0 there, see stream_end_overhang_candidates).  The occurrences of a first block close enough to
-      // the end for that come from the host; duplicates leave with the dedup.
+      // the whole pattern.  A pattern that hangs over the end of the stream has no such window (the extension DP reads
+      // code 0 there, see stream_end_overhang_candidates), and at the start of the stream the windows that do not
+      // fit are not seeded (a pattern whose first characters are deleted there ends in them).  Every block occurrence
+      // in the first and last 56 characters therefore comes from the host as well -- more than needed: the
+      // reference extends EVERY occurrence, the records are verified by the same DP, duplicates leave with the dedup.
       std::vector<pm_hit> extra;
-      const int64_t n = h->n;
-      const int64_t need = std::min<int64_t>(n, 32 + 2 * h->cfg.k + 2);
-      uint8_t tail[64] = {0};
-      if (need > 0) {
-        if (h->h_text) memcpy(tail, h->h_text + (n - need), (size_t)need);
-        else HIP_TRY(h, hipMemcpy(tail, h->d_text + (n - need), (size_t)need, hipMemcpyDeviceToHost));
+      const int64_t n = h->n, E = std::min<int64_t>(n, 56);
+      uint8_t edge[2][64] = {{0}, {0}};
+      if (E > 0) {
+        if (h->h_text) { memcpy(edge[0], h->h_text, (size_t)E); memcpy(edge[1], h->h_text + (n - E), (size_t)E); }
+        else {
+          HIP_TRY(h, hipMemcpy(edge[0], h->d_text, (size_t)E, hipMemcpyDeviceToHost));
+          HIP_TRY(h, hipMemcpy(edge[1], h->d_text + (n - E), (size_t)E, hipMemcpyDeviceToHost));
+        }
       }
       for (size_t j = 0; j < h->pats.size(); ++j) {
         const Pattern &p = h->pats[j];
         const int L = (int)p.s.size();
         const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
-        if (es < ee || es == 0) continue;
-        for (int64_t b0 = std::max<int64_t>(n - need, n - L - 2 * h->cfg.k - 2); b0 + es <= n; ++b0) {
-          if (b0 < 0) continue;
-          bool ok = true;
-          for (int q = 0; q < es && ok; ++q) ok = (int)tail[need - (n - b0) + q] == h->alpha.nch[(unsigned char)p.s[q]];
-          const int64_t send = b0 + es;
-          if (ok && send > h->own_begin && send <= h->own_end) {
-            pm_hit x; x.end = send; x.pid = (uint32_t)(j + 1); x.k = 0; x.aux[0] = x.aux[1] = x.aux[2] = 0;
-            extra.push_back(x);
+        const bool prefix = es >= ee;                                // exact_bases.cc:139-150: the larger block decides
+        const int blk = prefix ? es : ee;
+        if (blk <= 0) continue;
+        const char *bs = p.s.data() + (prefix ? 0 : L - blk);
+        for (int side = 0; side < 2; ++side) {
+          if (side == 0 ? h->scan_begin != 0 : h->scan_end < n) continue;
+          const int64_t base = side == 0 ? 0 : n - E;                 // stream index of edge[side][0]
+          for (int64_t o = 0; o + blk <= E; ++o) {
+            if (side == 1 && base + o + blk <= E && h->scan_begin == 0) continue;   // (a short stream: already taken from its start)
+            bool ok = true;
+            for (int q = 0; q < blk && ok; ++q) ok = (int)edge[side][o + q] == h->alpha.nch[(unsigned char)bs[q]];
+            const int64_t send = base + o + blk;
+            if (ok && send > h->own_begin && send <= h->own_end) {
+              pm_hit x; x.end = send; x.pid = (uint32_t)(j + 1); x.k = 0; x.aux[0] = x.aux[1] = x.aux[2] = 0;
+              extra.push_back(x);
+            }
           }
         }
       }

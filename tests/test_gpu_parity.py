@@ -331,6 +331,43 @@ def test_edit_plan_matches_that_end_with_the_stream():
                 assert got == want, (tail_eos, sem, k, kernel, len(want), len(got), sorted(set(want) - set(got))[:5])
 
 
+@pytest.mark.parametrize("lead_eos", [False, True])
+def test_exact_bases_at_both_ends_of_the_stream(lead_eos):
+    """exact_bases extends every occurrence of the mandated block (exact_bases.cc:92-121): leftwards over however
+    much text there is in front (a pattern whose first characters are deleted at the start of the stream,
+    primer_alignment.cc:657-662), rightwards past the end.  On the seed family the block occurrences come from
+    whole-pattern windows, which do not exist there (scripts/fuzz_families.py seed 42595: hit at end 19)."""
+    table = b"ACGT\n"
+    rng = np.random.default_rng(42595)
+    rnd = lambda n: "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    body = rnd(3000)
+    raw = (("\n" if lead_eos else "") + body).encode()
+    pats = []
+    for L in (20, 22, 27, 32):
+        head, tail = body[:L], body[-L:]
+        for d in (0, 1, 2):
+            for site in (head, tail):
+                pats.append(site[d:] + rnd(d))                      # first d characters gone (the last ones random)
+                pats.append(rnd(d) + site[:L - d])                  # shifted right: the last d characters hang over
+                pats.append(synth.mutate(rng, site[d:] + site[:d], nsub=1))
+                if d:
+                    pats.append(site[:3] + site[3 + d:] + rnd(d))   # d characters deleted inside
+                    pats.append(site[:L - 4 - d] + site[L - 4:] + rnd(d))
+    pats = [p for p in dict.fromkeys(pats) if 20 <= len(p) <= 32]
+    codes = synth.normalize(raw, table)
+    text = O.Text(codes, table)
+    found = 0
+    for esb, eeb in [(8, 0), (0, 8), (6, 7), (7, 6)]:
+        E, F = [esb] * len(pats), [eeb] * len(pats)
+        for k, ind in [(1, True), (2, True), (1, False), (2, False)]:
+            want = O.sorted_tuples(O.find_all(text, pats, engine=8, k=k, indels=ind, esb=E, eeb=F))
+            found += len([h for h in want if h[0] < 40 or h[0] > len(raw) - 3])
+            for kernel in (sat_amd.KERNEL_SEED, sat_amd.KERNEL_BITPAR):
+                got = gpu_hits(codes, table, pats, sat_amd.SEM_EXACT_BASES, k, ind, kernel, esb=E, eeb=F)
+                assert got == want, (lead_eos, esb, eeb, k, ind, kernel, len(want), len(got), sorted(set(want) - set(got))[:4], sorted(set(got) - set(want))[:4])
+    assert found > 40, found
+
+
 def test_candidate_overflow_is_reported_and_recovered():
     table = b"ACGT\n"
     codes = synth.normalize(("\n" + "A" * 5000 + "\n").encode(), table)
