@@ -1774,7 +1774,10 @@ extern "C" int pm_finalize_device_owned(pm_handle *h, const void *d_cands, size_
                                         int64_t guard_lo, int64_t guard_hi, int flags, pm_hit *out, size_t cap, size_t *n_out) {
   if (!(guard_lo <= own_lo && own_lo <= own_hi && own_hi <= guard_hi))
     return fail(h, PM_E_INVALID, "pm_finalize_device_owned: need guard_lo <= own_lo <= own_hi <= guard_hi");
-  const OwnedRange own = {own_lo, own_hi, guard_lo, guard_hi, 1};
+  // the shard that holds the true end of the stream also owns the hits that end beyond it (extensions that read
+  // past the end, stream_end_overhang_candidates)
+  const bool to_the_end = h && guard_hi == INT64_MAX && own_hi >= h->n;
+  const OwnedRange own = {own_lo, to_the_end ? INT64_MAX : own_hi, guard_lo, guard_hi, 1};
   return finalize_device_impl(h, d_cands, n, guard_hi == INT64_MAX ? h->n : guard_hi, flags | PM_FINALIZE_LAST, own, out, cap, n_out);
 }
 

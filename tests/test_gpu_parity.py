@@ -293,6 +293,20 @@ def test_extensions_read_past_the_end_of_the_stream(norm):
             for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED):
                 got = gpu_hits(data, tb, use, sat_amd.SEM_EXACT_BASES, k, ind, kernel, esb=E, eeb=F)
                 assert got == want, (norm, esb, eeb, k, ind, kernel, len(want), len(got), sorted(set(want) - set(got))[:4])
+            if not ind:
+                # two position shards (pm_finalize_device_owned): the one with the end of the stream owns what ends beyond it
+                pm = sat_amd.PatternMatch(k=k, indels=False, semantics=sat_amd.SEM_EXACT_BASES, kernel=sat_amd.KERNEL_SEED)
+                for i, p in enumerate(use):
+                    pm.add_pattern(p, i + 1, esb, eeb)
+                pm.init(data, tb)
+                n, cut, guard, parts = len(raw), 700, 200, []
+                for own_lo, own_hi in ((0, cut), (cut, n)):
+                    g_lo, g_hi = max(0, own_lo - guard), min(n, own_hi + guard)
+                    pm.reset()
+                    pm.scan_candidates(g_lo, g_hi, to_host=False)
+                    parts += sat_amd.sorted_tuples(pm.finalize_device(0, sort=True, owned=(own_lo, own_hi, g_lo, None if g_hi == n else g_hi)))
+                pm.close()
+                assert sorted(parts) == want, (norm, esb, eeb, k, len(want), len(parts))
 
 
 def test_edit_plan_matches_that_end_with_the_stream():
