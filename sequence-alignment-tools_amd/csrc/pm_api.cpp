@@ -80,6 +80,10 @@ struct pm_handle {
   bool start_cached = false;
   std::vector<pm_hit> end_cache;      // edits: candidates that end in the last four characters (scans that reach the end of the stream)
   bool end_cached = false;
+  std::vector<pm_hit> overhang_cache; // exact_halves / exact_bases -K: hits that hang over the end of the stream
+  bool overhang_cached = false;
+  std::vector<pm_hit> edge_cache;     // exact_bases -k: block occurrences in the first and last 56 characters
+  bool edge_cached = false;
   uint8_t *d_dp_codes = nullptr;      // device DP (pm_cluster_dp): 32 stream codes per pattern, exact zones
   int32_t *d_dp_esb = nullptr, *d_dp_eeb = nullptr;
   pm_hit *d_ext = nullptr;            // its output (swapped with d_cands after every scan)
@@ -439,7 +443,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->seed_flags = false; h->bases_flags = false; h->bases_edits = false; h->half_ranked_any = false;
   h->zoned = false;
   for (const Pattern &p : h->pats) h->zoned = h->zoned || p.esb || p.eeb;
-  h->start_cached = false; h->start_cache.clear(); h->end_cached = false; h->end_cache.clear();
+  h->start_cached = false; h->start_cache.clear(); h->end_cached = false; h->end_cache.clear(); h->overhang_cached = false; h->overhang_cache.clear(); h->edge_cached = false; h->edge_cache.clear();
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
   // A pattern set is rarely uniform: a few primers with an ambiguity letter, one that is too short
@@ -1086,46 +1090,51 @@ static int stream_start_candidates(pm_handle *h) {
 static int stream_end_overhang_candidates(pm_handle *h, bool bases) {
   const int k = h->cfg.k;
   const int64_t n = h->n;
-  const int64_t need = std::min<int64_t>(n, 32);
-  uint8_t tail[32] = {0};                                           // tail[32 - need .. 32) = the last `need` characters
-  if (need > 0) {
-    if (h->h_text) memcpy(tail + 32 - need, h->h_text + (n - need), (size_t)need);
-    else HIP_TRY(h, hipMemcpy(tail + 32 - need, h->d_text + (n - need), (size_t)need, hipMemcpyDeviceToHost));
-  }
-  auto differs = [&](unsigned char pc, int code) -> bool {
-    if (h->cfg.wildcards) return acgt_of(pc).find((char)h->alpha.ch[code]) == std::string::npos;
-    return code != h->alpha.nch[pc];
-  };
-  std::vector<pm_hit> extra;
-  if (h->eos_code != 0) {                                           // (code 0 = EOS: the extension's first character past the end is a violation)
-    for (size_t j = 0; j < h->pats.size(); ++j) {
-      const Pattern &p = h->pats[j];
-      const int L = (int)p.s.size();
-      const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
-      // the part found as an exact seed inside the stream: the left half (exact_halves), the mandated first block
-      // (exact_bases with esb >= eeb, exact_bases.cc:139-150; a last block lies on the stream with all of its pattern)
-      if (bases && (es < ee || es == 0)) continue;
-      const int len1 = bases ? es : L / 2, len2 = L - len1;
-      for (int t = 1; t <= len2; ++t) {
-        const int inside = L - t;                                   // pattern characters 0 .. inside-1 lie on the stream's last ones
-        if (inside > need) break;
-        int lvl = 0;
-        bool dead = false;
-        for (int i = 0; i < L && !dead; ++i) {
-          const int code = i < inside ? (int)tail[32 - inside + i] : 0;
-          if (i < inside && code == h->eos_code) dead = true;
-          else if (differs((unsigned char)p.s[i], code)) {
-            if (i < len1 || i < es || i >= L - ee) dead = true;     // the seed half is exact; a substitution in an exact zone is a violation
-            else ++lvl;
+  if (!h->overhang_cached) {                                        // same stream, same patterns: computed once
+    std::vector<pm_hit> &all = h->overhang_cache;
+    all.clear();
+    const int64_t need = std::min<int64_t>(n, 32);
+    uint8_t tail[32] = {0};                                         // tail[32 - need .. 32) = the last `need` characters
+    if (need > 0) {
+      if (h->h_text) memcpy(tail + 32 - need, h->h_text + (n - need), (size_t)need);
+      else HIP_TRY(h, hipMemcpy(tail + 32 - need, h->d_text + (n - need), (size_t)need, hipMemcpyDeviceToHost));
+    }
+    auto differs = [&](unsigned char pc, int code) -> bool {
+      if (h->cfg.wildcards) return acgt_of(pc).find((char)h->alpha.ch[code]) == std::string::npos;
+      return code != h->alpha.nch[pc];
+    };
+    if (h->eos_code != 0) {                                         // (code 0 = EOS: the extension's first character past the end is a violation)
+      for (size_t j = 0; j < h->pats.size(); ++j) {
+        const Pattern &p = h->pats[j];
+        const int L = (int)p.s.size();
+        const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
+        // the part found as an exact seed inside the stream: the left half (exact_halves), the mandated first block
+        // (exact_bases with esb >= eeb, exact_bases.cc:139-150; a last block lies on the stream with all of its pattern)
+        if (bases && (es < ee || es == 0)) continue;
+        const int len1 = bases ? es : L / 2, len2 = L - len1;
+        for (int t = 1; t <= len2; ++t) {
+          const int inside = L - t;                                 // pattern characters 0 .. inside-1 lie on the stream's last ones
+          if (inside > need) break;
+          int lvl = 0;
+          bool dead = false;
+          for (int i = 0; i < L && !dead; ++i) {
+            const int code = i < inside ? (int)tail[32 - inside + i] : 0;
+            if (i < inside && code == h->eos_code) dead = true;
+            else if (differs((unsigned char)p.s[i], code)) {
+              if (i < len1 || i < es || i >= L - ee) dead = true;   // the seed part is exact; a substitution in an exact zone is a violation
+              else ++lvl;
+            }
           }
-        }
-        if (!dead && lvl <= k) {
-          pm_hit x; x.end = n + t; x.pid = bases ? (uint32_t)p.id : (uint32_t)(j + 1); x.k = (uint8_t)lvl; x.aux[0] = bases ? 0 : 1; x.aux[1] = x.aux[2] = 0;
-          extra.push_back(x);
+          if (!dead && lvl <= k) {
+            pm_hit x; x.end = n + t; x.pid = bases ? (uint32_t)p.id : (uint32_t)(j + 1); x.k = (uint8_t)lvl; x.aux[0] = bases ? 0 : 1; x.aux[1] = x.aux[2] = 0;
+            all.push_back(x);
+          }
         }
       }
     }
+    h->overhang_cached = true;
   }
+  const std::vector<pm_hit> &extra = h->overhang_cache;
   if (extra.empty()) return PM_OK;
   if (h->last_count + extra.size() > h->cap) {
     h->overflow_need = h->last_count + extra.size();
@@ -1231,38 +1240,41 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
       // fit are not seeded (a pattern whose first characters are deleted there ends in them).  Every block occurrence
       // in the first and last 56 characters therefore comes from the host as well -- more than needed: the
       // reference extends EVERY occurrence, the records are verified by the same DP, duplicates leave with the dedup.
-      std::vector<pm_hit> extra;
       const int64_t n = h->n, E = std::min<int64_t>(n, 56);
-      uint8_t edge[2][64] = {{0}, {0}};
-      if (E > 0) {
-        if (h->h_text) { memcpy(edge[0], h->h_text, (size_t)E); memcpy(edge[1], h->h_text + (n - E), (size_t)E); }
-        else {
-          HIP_TRY(h, hipMemcpy(edge[0], h->d_text, (size_t)E, hipMemcpyDeviceToHost));
-          HIP_TRY(h, hipMemcpy(edge[1], h->d_text + (n - E), (size_t)E, hipMemcpyDeviceToHost));
+      if (!h->edge_cached) {                                        // same stream, same patterns: computed once
+        uint8_t edge[2][64] = {{0}, {0}};
+        if (E > 0) {
+          if (h->h_text) { memcpy(edge[0], h->h_text, (size_t)E); memcpy(edge[1], h->h_text + (n - E), (size_t)E); }
+          else {
+            HIP_TRY(h, hipMemcpy(edge[0], h->d_text, (size_t)E, hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipMemcpy(edge[1], h->d_text + (n - E), (size_t)E, hipMemcpyDeviceToHost));
+          }
         }
-      }
-      for (size_t j = 0; j < h->pats.size(); ++j) {
-        const Pattern &p = h->pats[j];
-        const int L = (int)p.s.size();
-        const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
-        const bool prefix = es >= ee;                                // exact_bases.cc:139-150: the larger block decides
-        const int blk = prefix ? es : ee;
-        if (blk <= 0) continue;
-        const char *bs = p.s.data() + (prefix ? 0 : L - blk);
-        for (int side = 0; side < 2; ++side) {
-          if (side == 0 ? h->scan_begin != 0 : h->scan_end < n) continue;
-          const int64_t base = side == 0 ? 0 : n - E;                 // stream index of edge[side][0]
-          for (int64_t o = 0; o + blk <= E; ++o) {
-            if (side == 1 && base + o + blk <= E && h->scan_begin == 0) continue;   // (a short stream: already taken from its start)
-            bool ok = true;
-            for (int q = 0; q < blk && ok; ++q) ok = (int)edge[side][o + q] == h->alpha.nch[(unsigned char)bs[q]];
-            const int64_t send = base + o + blk;
-            if (ok && send > h->own_begin && send <= h->own_end) {
-              pm_hit x; x.end = send; x.pid = (uint32_t)(j + 1); x.k = 0; x.aux[0] = x.aux[1] = x.aux[2] = 0;
-              extra.push_back(x);
+        h->edge_cache.clear();
+        for (size_t j = 0; j < h->pats.size(); ++j) {
+          const Pattern &p = h->pats[j];
+          const int L = (int)p.s.size();
+          const int es = std::max(0, std::min(L, p.esb)), ee = std::max(0, std::min(L, p.eeb));
+          const bool prefix = es >= ee;                              // exact_bases.cc:139-150: the larger block decides
+          const int blk = prefix ? es : ee;
+          if (blk <= 0) continue;
+          const char *bs = p.s.data() + (prefix ? 0 : L - blk);
+          for (int side = 0; side < 2; ++side) {
+            const int64_t base = side == 0 ? 0 : n - E;               // stream index of edge[side][0]
+            for (int64_t o = 0; o + blk <= E; ++o) {
+              if (side == 1 && base + o + blk <= E) continue;         // (a short stream: already taken from its start)
+              bool ok = true;
+              for (int q = 0; q < blk && ok; ++q) ok = (int)edge[side][o + q] == h->alpha.nch[(unsigned char)bs[q]];
+              if (ok) { pm_hit x; x.end = base + o + blk; x.pid = (uint32_t)(j + 1); x.k = 0; x.aux[0] = x.aux[1] = x.aux[2] = 0; h->edge_cache.push_back(x); }
             }
           }
         }
+        h->edge_cached = true;
+      }
+      std::vector<pm_hit> extra;
+      for (const pm_hit &x : h->edge_cache) {
+        if (!((x.end <= E && h->scan_begin == 0) || (x.end > n - E && h->scan_end >= n))) continue;   // the edge(s) this scan covers
+        if (x.end > h->own_begin && x.end <= h->own_end) extra.push_back(x);
       }
       if (tot + extra.size() > h->cap) { h->last_count = 0; if (n_out) *n_out = tot + extra.size(); return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
       if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
