@@ -2,7 +2,7 @@
 # round-3 profiles, stage 1: probes, kernel-trace stats of every bench option set, PMC passes (fabric traffic, pipe counters)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_r03
-for p in tcp_gather pipe_overlap valu_rate; do timeout -k 10 120 scripts/probe/$p > gpurun_out/prof_r03/probe_$p.txt 2>&1; echo "probe $p rc=$?"; done
+for p in tcp_gather pipe_overlap valu_rate pack_rate; do timeout -k 10 120 scripts/probe/$p > gpurun_out/prof_r03/probe_$p.txt 2>&1; echo "probe $p rc=$?"; done
 kt() { name=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03/kt_$name -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > gpurun_out/prof_r03/kt_$name.log 2>&1; echo "kernel-trace $name rc=$?"; }
 kt K2 --k 2
 kt K0 --k 0
