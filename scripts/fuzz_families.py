@@ -132,12 +132,24 @@ def main():
         rng = np.random.default_rng(seed)
         style = int(rng.integers(0, 4))
         n = int(rng.integers(1 << 16, 1 << 21))
-        s = make_stream(rng, n, style)
+        # one case in twelve: a long stream (the launch geometry large ranges get, long stretches without a key hit)
+        big = bool(rng.integers(0, 12) == 0)
+        if big:
+            n = int(rng.integers(20_000_000, 400_000_000))
+            g = torch.Generator(device="cuda")
+            g.manual_seed(seed)
+            dev_big = torch.randint(0, 4, (n,), dtype=torch.uint8, device="cuda", generator=g)
+            for _ in range(int(rng.integers(0, 4))):
+                dev_big[int(rng.integers(0, n))] = 4
+            s = dev_big[: 1 << 20].cpu().numpy()                      # the primers are cut from the first Mi characters
+            style = 0
+        else:
+            s = make_stream(rng, n, style)
         k = int(rng.integers(0, 3))
         indels = bool(rng.integers(0, 2)) and k > 0
         only20 = bool(rng.integers(0, 2))
         lo, hi = (20, 20) if only20 else (int(rng.integers(12, 21)), int(rng.integers(21, 33)))
-        count = int(rng.integers(1, 1500))
+        count = int(rng.integers(1, 300 if big else 1500))
         pats = make_patterns(rng, s, count, lo, hi, k)
         allp = pats + [sat_amd.reverse_comp(p) for p in pats]
         sem, sname = sems[int(rng.integers(0, len(sems)))]
@@ -177,10 +189,16 @@ def main():
         mode = int(rng.integers(0, 4))
         raw = bool(rng.integers(0, 4) == 0)                            # the stream as bytes 'A','C','G','T','\n' with no table
         table = None if raw else (b"ACGT\nN" if with_n else TABLE)
-        if with_n:
-            s = s.copy()
-            s[rng.integers(0, n, int(rng.integers(1, 200)))] = 5
-        dev = torch.from_numpy(np.frombuffer(b"ACGT\nN", dtype=np.uint8)[s] if raw else s).cuda()
+        if big:
+            with_n = False
+            table = None if raw else TABLE
+            dev = torch.from_numpy(np.frombuffer(b"ACGT\nN", dtype=np.uint8).copy()).cuda()[dev_big.long()] if raw else dev_big
+            del dev_big
+        else:
+            if with_n:
+                s = s.copy()
+                s[rng.integers(0, n, int(rng.integers(1, 200)))] = 5
+            dev = torch.from_numpy(np.frombuffer(b"ACGT\nN", dtype=np.uint8)[s] if raw else s).cuda()
         t0 = time.time()
         try:
             b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24, 0, rng, table, zones, wild)
@@ -199,7 +217,7 @@ def main():
         same = a[0].size == b[0].size and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
         cases += 1
         print("seed %d mode %d%s%s%s%s style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
-            seed, mode, " raw" if raw else "", " zones" if zones else "", " wild" if wild else "", " N" if with_n else "", style, n, k, indels, lo, hi, 2 * count, sname, cap,
+            seed, mode, " raw" if raw else "", " zones" if zones else "", " wild" if wild else "", " N" if with_n else "", style + (10 if big else 0), n, k, indels, lo, hi, 2 * count, sname, cap,
             ",".join("%s=%s" % (e[3:], os.environ[e]) for e in ("PM_SEED_CHUNK", "PM_PAIR_ROW", "PM_SEED_GROUP", "PM_SEED_TILE") if e in os.environ),
             a[0].size, "ok" if same else "DIFFERENT (bitpar %d)" % b[0].size, time.time() - t0, a[4][:60]), flush=True)
         if not same:
