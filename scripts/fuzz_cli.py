@@ -66,6 +66,17 @@ def primer_round(seed, d):
             if differ("primer_match seed %d %s %s" % (seed, cname, variant), ref.stdout, ours.stdout):
                 return -1
             n += 1
+            # the reference's own main() on the GPU engine (oracle/_ref/primer_match_gpu: its primer_match.o linked with
+            # class gpu_pattern_match, host/plugin/), on the uncompressed database forms
+            plug = os.path.join(REF, "primer_match_gpu")
+            if os.path.exists(plug) and variant != "compressed" and "-N" not in extra:
+                mine = run([plug, "-i", fa] + parg + extra + ["-N", "17"])
+                if mine.returncode != 0:
+                    print("DIFFERENT primer_match_gpu seed %d %s %s: failed: %s" % (seed, cname, variant, mine.stderr[-300:]))
+                    return -1
+                if differ("primer_match_gpu seed %d %s %s" % (seed, cname, variant), ref.stdout, mine.stdout):
+                    return -1
+                n += 1
     return n
 
 
@@ -91,6 +102,15 @@ def pcr_round(seed, d):
                 print("DIFFERENT pcr_match seed %d %s %s: ours failed: %s" % (seed, cname, more, ours.stderr[-300:]))
                 return -1
             if differ("pcr_match seed %d %s %s" % (seed, cname, more), ref.stdout, ours.stdout):
+                return -1
+            n += 1
+        plug = os.path.join(REF, "pcr_match_gpu")
+        if os.path.exists(plug):
+            mine = run([plug, "-i", fa, flag, os.path.join(d, "primers." + src)] + extra + ["-N", "17"])
+            if mine.returncode != 0:
+                print("DIFFERENT pcr_match_gpu seed %d %s: failed: %s" % (seed, cname, mine.stderr[-300:]))
+                return -1
+            if differ("pcr_match_gpu seed %d %s" % (seed, cname), ref.stdout, mine.stdout):
                 return -1
             n += 1
     return n
