@@ -81,7 +81,7 @@ def sort3(end, pid, k):
     return end[o].astype(np.int64), pid[o].astype(np.int64), k[o].astype(np.int64)
 
 
-def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABLE, zones=None, wild=False):
+def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABLE, zones=None, wild=False, host=None):
     """mode 0: find_all over the whole stream; 1: find_all in small chunks (resumable scans); 2: one scan + the
     device finalize (bench.py's single-rank path); 3: two position shards, each finalized on its own with a guard
     band (bench.py's multi-rank path).  Raises PmError(-2) where the library says the mode does not apply."""
@@ -91,7 +91,10 @@ def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABL
             pm.add_pattern(p, i + 1)
         else:
             pm.add_pattern(p, i + 1, zones[i][0], zones[i][1])
-    pm.init_device(dev.data_ptr(), dev.numel(), table, keepalive=dev)
+    if host is not None:
+        pm.init(host, table)                                           # the stream handed over in host memory (pm_init uploads it)
+    else:
+        pm.init_device(dev.data_ptr(), dev.numel(), table, keepalive=dev)
     pm.set_capacity(cap)
     n = dev.numel()
     try:
@@ -187,6 +190,7 @@ def main():
                 os.environ[name] = v
         cap = [1 << 12, 1 << 18, 1 << 24][int(rng.integers(0, 3))]
         mode = int(rng.integers(0, 4))
+        host = None
         raw = bool(rng.integers(0, 4) == 0)                            # the stream as bytes 'A','C','G','T','\n' with no table
         table = None if raw else (b"ACGT\nN" if with_n else TABLE)
         if big:
@@ -198,16 +202,21 @@ def main():
             if with_n:
                 s = s.copy()
                 s[rng.integers(0, n, int(rng.integers(1, 200)))] = 5
+            if not raw and rng.integers(0, 8) == 0:                    # the end-of-entry character first in the table (code 0)
+                table = b"\nACGT" + (b"N" if with_n else b"")
+                s = np.array([1, 2, 3, 4, 0, 5], dtype=np.uint8)[s]
             dev = torch.from_numpy(np.frombuffer(b"ACGT\nN", dtype=np.uint8)[s] if raw else s).cuda()
+            if rng.integers(0, 4) == 0:
+                host = dev.cpu().numpy()
         t0 = time.time()
         try:
-            b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24, 0, rng, table, zones, wild)
+            b = hits_of(allp, k, indels, sat_amd.KERNEL_BITPAR, sem, dev, 1 << 24, 0, rng, table, zones, wild, host)
         except sat_amd.PmError as err:                                 # an option set the reference rejects as well (e.g. k too large for the zones)
             print("seed %d skipped: the bit-parallel family says %s" % (seed, str(err)[:100]), flush=True)
             seed += 1
             continue
         try:
-            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap, mode, rng, table, zones, wild)
+            a = hits_of(allp, k, indels, sat_amd.KERNEL_SEED, sem, dev, cap, mode, rng, table, zones, wild, host)
         except sat_amd.PmError as err:
             if err.code == -2 or "chain" in str(err):                  # option set / mode the library does not cover: said loudly
                 print("seed %d mode %d skipped (%s)" % (seed, mode, str(err)[:100]), flush=True)
@@ -217,7 +226,7 @@ def main():
         same = a[0].size == b[0].size and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
         cases += 1
         print("seed %d mode %d%s%s%s%s style %d n %d k %d indels %d L %d..%d patterns %d sem %s cap %d env %s: %d hits %s  %.1f s  %s" % (
-            seed, mode, " raw" if raw else "", " zones" if zones else "", " wild" if wild else "", " N" if with_n else "", style + (10 if big else 0), n, k, indels, lo, hi, 2 * count, sname, cap,
+            seed, mode, " raw" if raw else "", " zones" if zones else "", " wild" if wild else "", (" N" if with_n else "") + (" host" if host is not None else "") + (" eos0" if table and table[:1] == b"\n" else ""), style + (10 if big else 0), n, k, indels, lo, hi, 2 * count, sname, cap,
             ",".join("%s=%s" % (e[3:], os.environ[e]) for e in ("PM_SEED_CHUNK", "PM_PAIR_ROW", "PM_SEED_GROUP", "PM_SEED_TILE") if e in os.environ),
             a[0].size, "ok" if same else "DIFFERENT (bitpar %d)" % b[0].size, time.time() - t0, a[4][:60]), flush=True)
         if not same:
