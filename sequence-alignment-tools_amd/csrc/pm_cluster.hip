@@ -53,8 +53,8 @@ __device__ __forceinline__ bool hit_owned(const OwnedRange &own, int64_t end) {
 }
 
 // One thread per sorted key; a chain's head walks it.  The final hits leave block by block: one atomic on the shared
-// counter per 256 keys (one per wave -- 15k same-address atomics for the 10^6 hits of a 3 Gbp -K 2 scan -- was most of
-// this kernel's 0.19 ms).
+// counter per 256 keys (one per wave -- 15k same-address atomics for the 10^6 hits of a 3 Gbp -K 2 scan -- took this
+// kernel 0.19 ms; block by block: 0.05 ms, profiles/r03_kernel_stats_K2.csv).
 __global__ __launch_bounds__(256) void pm_cluster_reduce(const uint64_t *keys, size_t n, int win, int64_t scanned_to, int last, int invalid_level,
                                                          const uint8_t *pat_len, const uint32_t *pat_id, OwnedRange own,
                                                          pm_hit *out, unsigned long long *out_count,
