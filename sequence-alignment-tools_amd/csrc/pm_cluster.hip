@@ -135,8 +135,11 @@ __global__ void pm_dedup_pack(const pm_hit *in, size_t n, uint64_t *keys) {
                                   : ((uint64_t)h.pid << 42) | (((uint64_t)h.end & 0xffffffffffull) << 2) | (uint64_t)(h.k & 3u);
 }
 
-// keys sorted: equal (pattern, end) are adjacent and the smallest level comes first
-__global__ void pm_dedup_unpack(const uint64_t *keys, size_t n, pm_hit *out, unsigned long long *count) {
+// keys sorted: equal (pattern, end) are adjacent and the smallest level comes first.  The unique records leave block
+// by block (one atomic per 256 keys; one per wave took 1.04 ms for the 7·10^6 records of a 3 Gbp -k 2 scan).
+__global__ __launch_bounds__(256) void pm_dedup_unpack(const uint64_t *keys, size_t n, pm_hit *out, unsigned long long *count) {
+  __shared__ uint32_t s_cnt[4];
+  __shared__ unsigned long long s_base;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   bool head = false;
   uint64_t key = 0;
@@ -145,16 +148,21 @@ __global__ void pm_dedup_unpack(const uint64_t *keys, size_t n, pm_hit *out, uns
     head = key != DEDUP_HOLE && (i == 0 || (keys[i - 1] >> 2) != (key >> 2));
   }
   const unsigned long long bal = __ballot(head);
-  if (bal == 0) return;
-  const int lane = threadIdx.x & 63;
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(bal));
-  base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
   if (head) {
+    unsigned long long o = s_base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) o += s_cnt[w];
     pm_hit h;
     h.pid = (uint32_t)(key >> 42); h.end = (int64_t)((key >> 2) & 0xffffffffffull); h.k = (uint8_t)(key & 3u);
     h.aux[0] = h.aux[1] = h.aux[2] = 0;
-    out[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))] = h;
+    out[o] = h;
   }
 }
 
