@@ -128,3 +128,61 @@ def test_fuzz_wildcards_inexact_against_reference(ref_harness, seed):
                         assert got == ref, (seed, flag, k, indels, sel, len(got), len(ref))
                         total += len(ref)
     assert total > 0
+
+
+@pytest.mark.parametrize("norm", [True, False])
+def test_stream_edges_against_reference(ref_harness, norm):
+    """The quirks at the ends of the stream that round 3's GPU fixes rest on (tests/test_gpu_parity.py:
+    test_extensions_read_past_the_end_of_the_stream, test_exact_bases_at_both_ends_of_the_stream,
+    test_edit_plan_matches_that_end_with_the_stream): the reference's extensions read the mapped file's zero padding
+    past the last character (mapFile.h:49-57) and report hits that end beyond the stream; a pattern whose first
+    characters are deleted matches at the very start.  The oracle must say what the REAL reference says there."""
+    import os, subprocess, tempfile
+    table = b"ACGT\n"
+    rng = np.random.default_rng(90)
+    rnd = lambda n: "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    body = rnd(1500)
+    tail = "GATTACAGGCTTACCGTCAATGCCTGAAGTCCATGTTGCA"
+    raw = ("\n" + body + tail).encode()
+    pats = []
+    for L in (14, 20, 21, 24, 32):
+        len2 = L - L // 2
+        for t in range(1, len2 + 2):
+            p = tail[len(tail) - (L - t):] + "A" * t                 # hangs over the end by t characters
+            pats += [p, p[:-1] + "C", "ACGT"[("ACGT".index(p[0]) + 2) % 4] + p[1:]]
+            if t >= 2:
+                pats.append(p[:-2] + "CG")
+        head = body[:L]
+        pats += [head[1:] + "A", head[2:] + "AC", head[:3] + head[4:] + "G"]       # first characters deleted at the start
+        site = (body + tail)[-L:]
+        pats += [site[:L - 3] + "C" + site[L - 3:], site[:L - 1] + "GG"]            # deleted pattern characters at the very end
+    pats = list(dict.fromkeys(pats))
+    data = synth.normalize(raw, table) if norm else np.frombuffer(raw, dtype=np.uint8)
+    text = O.Text(data, table) if norm else O.Text(data)
+    beyond = 0
+    for sel, k, ind in [(12, 0, 0), (12, 1, 0), (12, 2, 0), (12, 1, 1), (12, 2, 1), (100, 2, 1), (100, 2, 0), (5, 2, 1), (5, 1, 1)]:
+        use = [p for p in pats if len(p) >= 16] if (ind and sel == 12) else pats
+        ref = refrun.run_ref(ref_harness, data, use, table=table if norm else None, sel=sel, k=k, indels=bool(ind))
+        got = O.sorted_tuples(O.find_all(text, use, engine=sel, k=k, indels=bool(ind)))
+        assert got == ref, (norm, sel, k, ind, sorted(set(ref) - set(got))[:4], sorted(set(got) - set(ref))[:4])
+        beyond += len([h for h in ref if h[0] > len(raw)])
+    assert beyond > (100 if norm else 20)                      # (on a raw stream every character past the end is a substitution)
+    # exact_bases (-s / -e), prefix and suffix blocks
+    use = [p for p in pats if len(p) >= 20]
+    with tempfile.TemporaryDirectory() as d:
+        if norm:
+            open(os.path.join(d, "db.sqn"), "wb").write(data.tobytes())
+            open(os.path.join(d, "db.tbl"), "wb").write(table)
+        else:
+            open(os.path.join(d, "db"), "wb").write(raw)
+        open(os.path.join(d, "pat.txt"), "w").write("\n".join(use) + "\n")
+        for esb, eeb in [(8, 0), (6, 3), (0, 7)]:
+            for k, ind in [(1, 0), (2, 0), (1, 1), (2, 1)]:
+                cmd = [ref_harness, "-N", "8", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt"), "-s", str(esb), "-e", str(eeb),
+                       "-k" if ind else "-K", str(k)] + (["-n"] if norm else [])
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                assert out.returncode == 0, out.stderr[-300:]
+                ref = sorted(tuple(int(x) for x in l.split()) for l in out.stdout.splitlines() if not l.startswith("#"))
+                E, F = [esb] * len(use), [eeb] * len(use)
+                got = O.sorted_tuples(O.find_all(text, use, engine=8, k=k, indels=bool(ind), esb=E, eeb=F))
+                assert got == ref, (norm, esb, eeb, k, ind, sorted(set(ref) - set(got))[:4], sorted(set(got) - set(ref))[:4])
