@@ -1,0 +1,76 @@
+"""CPU, build container only: fuzz the oracle (oracle/pm_oracle.c, test infrastructure) against the REAL reference
+engines (oracle/_ref/ref_harness, the reference's sources compiled where they lie) on the adversarial streams of
+scripts/fuzz_families.py -- skewed composition, words of a small vocabulary, tandem repeats with drifting copies,
+primers cut from the stream and edited -- at sizes the reference finishes in seconds.  The oracle is what the GPU
+parity tests compare with; this is what pins it beyond the committed goldens.
+
+    python scripts/fuzz_oracle.py [seconds] [first_seed]
+
+Exit status 1 on the first difference."""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+if "torch" not in sys.modules:                                     # the generators of fuzz_families do not need it
+    sys.modules["torch"] = types.ModuleType("torch")
+import fuzz_families as F  # noqa: E402
+import refrun  # noqa: E402
+from oracle import pmoracle as O  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+# (engine selector of ref_harness, k, indels)
+CONFIGS = [(0, 0, 1), (4, 0, 1), (2, 0, 1), (100, 1, 0), (100, 2, 0), (100, 2, 1), (100, 1, 1), (5, 1, 1), (5, 2, 0), (5, 2, 1), (5, 1, 0),
+           (12, 0, 0), (12, 1, 0), (12, 2, 0), (12, 1, 1), (14, 1, 1), (12, 2, 1), (0, 1, 1), (0, 1, 0), (0, 2, 1), (0, 2, 0)]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t_end = time.time() + budget
+    runs = 0
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        style = int(rng.integers(0, 4))
+        n = int(rng.integers(200, 6000))
+        s = F.make_stream(rng, n, style)
+        lo, hi = (20, 20) if rng.integers(0, 2) else (int(rng.integers(8, 21)), int(rng.integers(21, 33)))
+        pats = F.make_patterns(rng, s, int(rng.integers(1, 40)), lo, min(hi, n - 1), 2)
+        raw = np.frombuffer(b"ACGT\n", dtype=np.uint8)[s]
+        norm = bool(rng.integers(0, 2))
+        rc = bool(rng.integers(0, 2))
+        allp = pats + [F.sat_amd.reverse_comp(p) for p in pats] if rc else pats
+        data, table = (s, b"ACGT\n") if norm else (raw, None)
+        text = O.Text(data, table) if norm else O.Text(data)
+        for sel, k, ind in CONFIGS:
+            try:
+                # one find_patterns call: the reference's keyword tree keeps a look-ahead character across calls and drops it --
+                # with the hits that end on it -- when a call returns right in front of the stream's last character
+                # (keyword_tree.t:434: `if ((eof=cp.eof())) return false;`); which hits are lost depends on where the calls
+                # happen to end, so the oracle (and the engines) state the answer of a single call.  A database written by
+                # compress_seq ends with an end-of-sequence character: no hit ends there.
+                ref = refrun.run_ref(HARNESS, data, pats, table=table, sel=sel, k=k, indels=bool(ind), rc=rc, minka=1000000)
+            except RuntimeError as e:                                  # the reference rejects the option set (e.g. k >= pattern length)
+                continue
+            eng = O.pick_engine(text, allp, k, bool(ind)) if sel == 0 else sel
+            got = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=bool(ind)))
+            runs += 1
+            if got != ref:
+                print("DIFFERENT seed %d style %d n %d norm %d rc %d engine %d k %d indels %d: reference %d hits, oracle %d" % (seed, style, n, norm, rc, sel, k, ind, len(ref), len(got)))
+                print("  only reference:", sorted(set(ref) - set(got))[:6], " only oracle:", sorted(set(got) - set(ref))[:6])
+                print("runs %d failures 1" % runs)
+                sys.exit(1)
+        if seed % 20 == 0:
+            print("seed %d ok (%d engine runs so far)" % (seed, runs), flush=True)
+        seed += 1
+    print("runs %d failures 0" % runs)
+
+
+if __name__ == "__main__":
+    main()
