@@ -8,7 +8,9 @@ parity tests compare with; this is what pins it beyond the committed goldens.
 
 Exit status 1 on the first difference."""
 import os
+import subprocess
 import sys
+import tempfile
 import time
 import types
 
@@ -66,6 +68,34 @@ def main():
                 print("  only reference:", sorted(set(ref) - set(got))[:6], " only oracle:", sorted(set(got) - set(ref))[:6])
                 print("runs %d failures 1" % runs)
                 sys.exit(1)
+        # exact_start_bases / exact_end_bases (-s / -e, the same for every pattern): exact_bases and the constrained verifies
+        esb, eeb = [(8, 0), (0, 7), (6, 9), (3, 0), (7, 6), (0, 0)][int(rng.integers(0, 6))]
+        if (esb or eeb) and all(len(p) >= 14 for p in pats):
+            with tempfile.TemporaryDirectory() as d:
+                if norm:
+                    open(os.path.join(d, "db.sqn"), "wb").write(data.tobytes())
+                    open(os.path.join(d, "db.tbl"), "wb").write(table)
+                else:
+                    open(os.path.join(d, "db"), "wb").write(data.tobytes())
+                open(os.path.join(d, "pat.txt"), "w").write("\n".join(pats) + "\n")
+                for sel, k, ind in [(0, 1, 1), (0, 2, 1), (0, 2, 0), (8, 1, 1), (8, 2, 1), (8, 1, 0), (10, 2, 0), (5, 2, 1), (5, 2, 0), (12, 1, 1), (12, 2, 0)]:
+                    cmd = [HARNESS, "-N", str(sel), "-m", "1000000", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt"), "-s", str(esb), "-e", str(eeb),
+                           "-k" if ind else "-K", str(k)] + (["-n"] if norm else []) + (["-r"] if rc else [])
+                    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                    if out.returncode != 0:
+                        continue
+                    ref = sorted(tuple(int(x) for x in l.split()) for l in out.stdout.splitlines() if not l.startswith("#"))
+                    E, Fz = [esb] * len(allp), [eeb] * len(allp)
+                    eng = sel if sel else O.pick_engine(text, allp, k, bool(ind), E, Fz)
+                    if eng < 0:
+                        continue
+                    got = O.sorted_tuples(O.find_all(text, allp, engine=eng, k=k, indels=bool(ind), esb=E, eeb=Fz))
+                    runs += 1
+                    if got != ref:
+                        print("DIFFERENT seed %d style %d n %d norm %d rc %d zones %d/%d engine %d k %d indels %d: reference %d hits, oracle %d" % (seed, style, n, norm, rc, esb, eeb, sel, k, ind, len(ref), len(got)))
+                        print("  only reference:", sorted(set(ref) - set(got))[:6], " only oracle:", sorted(set(got) - set(ref))[:6])
+                        print("runs %d failures 1" % runs)
+                        sys.exit(1)
         if seed % 20 == 0:
             print("seed %d ok (%d engine runs so far)" % (seed, runs), flush=True)
         seed += 1
