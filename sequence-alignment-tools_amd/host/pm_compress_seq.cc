@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
   if (database.empty()) usage("Arguement -i missing from commandline.");
   std::vector<unsigned char> in;
   if (!pmgpu::read_file(database, &in)) { fprintf(stderr, "Can't open %s\n", database.c_str()); return 1; }
+  if (in.empty()) return 0;                              // a file of no bytes: the reference writes nothing (its mapping has no characters to hand out) and exits 0
 
   std::vector<unsigned char> seq, hdr;
   std::vector<int64_t> idx;                            // (seqpos, headerpos) pairs

@@ -50,6 +50,8 @@ AWKWARD = [
     b"junk before the first header\n>only one\nACGT\n",
     b">ends inside a header",
     b">x\nACGT\n>y\n",
+    b"",                                                  # no bytes at all: the reference writes no files (scripts/fuzz_compress.py seed 31)
+    b"\n",
 ]
 
 
