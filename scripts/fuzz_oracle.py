@@ -44,6 +44,11 @@ def main():
         s = F.make_stream(rng, n, style)
         lo, hi = (20, 20) if rng.integers(0, 2) else (int(rng.integers(8, 21)), int(rng.integers(21, 33)))
         pats = F.make_patterns(rng, s, int(rng.integers(1, 40)), lo, min(hi, n - 1), 2)
+        # FUZZ_MINKA=random: many find_patterns calls of random size, on a stream that ends with an end-of-sequence
+        # character as every compress_seq database does (see the note at run_ref below)
+        many_calls = os.environ.get("FUZZ_MINKA") == "random"
+        if many_calls:
+            s = np.concatenate([s, np.array([4], dtype=np.uint8)])
         raw = np.frombuffer(b"ACGT\n", dtype=np.uint8)[s]
         norm = bool(rng.integers(0, 2))
         rc = bool(rng.integers(0, 2))
@@ -57,7 +62,7 @@ def main():
                 # (keyword_tree.t:434: `if ((eof=cp.eof())) return false;`); which hits are lost depends on where the calls
                 # happen to end, so the oracle (and the engines) state the answer of a single call.  A database written by
                 # compress_seq ends with an end-of-sequence character: no hit ends there.
-                ref = refrun.run_ref(HARNESS, data, pats, table=table, sel=sel, k=k, indels=bool(ind), rc=rc, minka=1000000)
+                ref = refrun.run_ref(HARNESS, data, pats, table=table, sel=sel, k=k, indels=bool(ind), rc=rc, minka=int(rng.integers(1, 50)) if many_calls else 1000000)
             except RuntimeError as e:                                  # the reference rejects the option set (e.g. k >= pattern length)
                 continue
             eng = O.pick_engine(text, allp, k, bool(ind)) if sel == 0 else sel
@@ -79,7 +84,7 @@ def main():
                     open(os.path.join(d, "db"), "wb").write(data.tobytes())
                 open(os.path.join(d, "pat.txt"), "w").write("\n".join(pats) + "\n")
                 for sel, k, ind in [(0, 1, 1), (0, 2, 1), (0, 2, 0), (8, 1, 1), (8, 2, 1), (8, 1, 0), (10, 2, 0), (5, 2, 1), (5, 2, 0), (12, 1, 1), (12, 2, 0)]:
-                    cmd = [HARNESS, "-N", str(sel), "-m", "1000000", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt"), "-s", str(esb), "-e", str(eeb),
+                    cmd = [HARNESS, "-N", str(sel), "-m", str(int(rng.integers(1, 50))) if many_calls else "1000000", "-i", os.path.join(d, "db"), "-P", os.path.join(d, "pat.txt"), "-s", str(esb), "-e", str(eeb),
                            "-k" if ind else "-K", str(k)] + (["-n"] if norm else []) + (["-r"] if rc else [])
                     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                     if out.returncode != 0:
