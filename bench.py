@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the all-cores figure (0 = every host core)")
     ap.add_argument("--no-check", action="store_true", help="do not require the planted primer sites in the result (kernel stage measurements with PM_SEED_DEBUG)")
     ap.add_argument("--dump-hits", default="", help="rank 0 writes the final hits of the last step (global stream indices, sorted) to this .npy file")
+    ap.add_argument("--scan-passes", type=int, default=3, help="timed whole-stream passes through pm_scan itself after the timed region (0 = skip; single GPU only)")
+    ap.add_argument("--scan-chunk", type=int, default=1 << 28, help="stream bytes per pm_scan range (the compiled plugin default)")
+    ap.add_argument("--scan-cap", type=int, default=1 << 20, help="records the caller takes per pm_scan call")
     ap.add_argument("--capacity", type=int, default=0, help="initial record capacity (0 = default; small values exercise the grow-and-rescan path)")
     args = ap.parse_args()
 
@@ -570,6 +573,33 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- the reference-facing call: PatternMatch::find_patterns = pm_scan (pattern_match.h:131, primer_match.cc:1118) ----
+    # One whole-stream pass as the compiled plugin makes it (host/plugin/gpu_pattern_match.cc): pm_reset, then consecutive
+    # ranges of --scan-chunk stream bytes, every range drained into the CALLER's (pageable) array, hits sorted by (end, pid).
+    # Wall clock from pm_reset to the last record resident in that array; not the headline `value` (which times the
+    # sharded step the multi-GPU contract describes), reported beside it.
+    pm_scan_ms, pm_scan_hits, scan_hits_arr = None, None, None
+    if not use_dist and args.scan_passes > 0:
+        torch.cuda.synchronize()
+        caller = np.zeros(1 << 24, dtype=sat_amd.HIT_DTYPE)
+        times = []
+        for _ in range(args.scan_passes + 1):                       # first pass untimed (buffers grow to their working size)
+            pm.reset()
+            t0s = time.perf_counter()
+            got, pos = 0, begin
+            while pos < end:
+                e2 = min(end, pos + args.scan_chunk)
+                cnt, more = pm.scan(pos, e2, caller[got:got + args.scan_cap])
+                got += cnt
+                while more:
+                    cnt, more = pm.scan(e2, e2, caller[got:got + args.scan_cap])
+                    got += cnt
+                pos = e2
+            times.append((time.perf_counter() - t0s) * 1e3)
+        pm_scan_ms, pm_scan_hits = float(np.mean(times[1:])), got
+        scan_hits_arr = caller[:got]
+        pm.reset()
+
     found_planted = None
     if rank == 0 and last_final[0] is not None:
         torch.cuda.synchronize()
@@ -578,6 +608,12 @@ def main():
         fin = fin[np.lexsort((fin["k"], fin["pid"], fin["end"]))]
         if args.dump_hits:
             np.save(args.dump_hits, fin)
+        if scan_hits_arr is not None:
+            # the same hits, already in (end, pid, k) order, through pm_scan as through the timed step
+            same = scan_hits_arr.size == fin.size and bool((scan_hits_arr["end"] == fin["end"]).all() and (scan_hits_arr["pid"] == fin["pid"]).all()
+                                                         and (scan_hits_arr["k"] == fin["k"]).all())
+            if not same:
+                raise SystemExit("bench.py: pm_scan returned %d hits that differ from the %d of the timed step (or are not sorted)" % (scan_hits_arr.size, fin.size))
         # every planted site within reach (distance <= k) must be reported: primer i (forward strand,
         # id i+1) with at most its planted distance, at the site's end -- filter_bitvec reports one hit
         # per chain of candidates and exact_halves drops hits within 2k of the last kept one, so the
@@ -625,6 +661,10 @@ def main():
             "ranks_seen": dist.get_world_size() if use_dist else 1, "pack_ms": pm.pack_time(),
             # the one-off 2-bit re-encoding of the stream (untimed, at init) charged to a single cold pass
             "value_including_pack": n_bases_total / (dt / args.steps + pm.pack_time() * 1e-3) / 1e9,
+            "pm_scan_ms": pm_scan_ms, "value_through_pm_scan": None if not pm_scan_ms else n_bases_total / (pm_scan_ms * 1e-3) / 1e9,
+            "pm_scan": None if not pm_scan_ms else {"hits": pm_scan_hits, "chunk_bytes": args.scan_chunk, "records_per_call": args.scan_cap, "passes": args.scan_passes,
+                        "what": "pm_reset + consecutive pm_scan ranges over the whole stream, every range drained into the caller's pageable array, "
+                                "hits sorted by (end, pid); equal to the timed step's hits (checked)"},
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%d x %d-mer primers, both strands (%d patterns), %s %d, %s Gbp stream in total = %s Gbp per GPU x %d GPU(s), %d entries"
                                    % (args.primers, args.length, len(allp), "-k" if args.indels else "-K", args.k,

@@ -112,6 +112,16 @@ int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *t
  * *more = 1 when out was too small: call again with begin == end to drain. */
 int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more);
 
+/* pm_scan without the copy: *hits points at the final hits of the range -- plus any an earlier pm_scan call left
+ * undrained -- in the handle's own (pinned) buffer, *n says how many; the span stays valid until the next call on the
+ * handle.  This is the form the PatternMatch plugin uses (host/plugin/gpu_pattern_match.cc): the reference's
+ * find_patterns appends to the caller's pattern_hit_vector (pattern_match.h:131), so the plugin pushes the records
+ * straight from this span.  Both forms share one pipeline: when the finalize stage of the option set runs on the GPU, the
+ * scan of the range expected next (the same number of stream bytes, as primer_match.cc:1118's loop walks the stream) is
+ * enqueued before the call returns, and the copy out of HBM, the caller's work on the hits and its next call overlap it.
+ * A different next range, pm_reset or pm_destroy simply let that scan finish unused. */
+int pm_scan_view(pm_handle *h, int64_t begin, int64_t end, const pm_hit **hits, size_t *n);
+
 /* Device stage only, position-independent (what shards across GPUs): candidate records for
  * begin < end_pos <= end.  Records stay in HBM (pm_candidates_device) and are copied to `out`
  * when it is not NULL.  PM_E_OVERFLOW if more than the internal capacity (pm_set_capacity). */

@@ -110,8 +110,18 @@ struct pm_handle {
   // host stage state
   std::vector<pm_hit> carry;          // filter_bitvec: candidates whose cluster is not complete yet
   std::vector<int64_t> lasthit;       // exact_halves: last kept end per pattern (exact_halves.cc:163)
-  std::vector<pm_hit> ready;          // final hits not yet handed out by pm_scan
-  size_t ready_pos = 0;
+  // pm_scan: the final hits of the ranges scanned so far, in (end, pid, k) order, in pinned host memory; handed out
+  // by pm_scan (copied) or pm_scan_view (as a span) from land_pos on
+  pm_hit *land = nullptr;
+  size_t land_cap = 0, land_n = 0, land_pos = 0;
+  hipStream_t copy_stream = nullptr;  // copies out of HBM that run beside the next range's scan (non-blocking stream)
+  hipEvent_t ev_fin = nullptr;        // "the finalize stage of this range is done" on the handle's stream
+  pm_hit *d_fsorted = nullptr;        // final hits after the device sort
+  size_t fsorted_cap = 0;
+  bool sort_dev = false;              // (end, pid, k) order by one keys-only radix sort on the device (device_sort_plan)
+  int sort_idxbits = 0, sort_keybits = 0;
+  bool spec = false;                  // pm_scan has the scan of the range it expects next in flight: (spec_b, spec_e]
+  int64_t spec_b = 0, spec_e = 0;
   int64_t next_begin = 0;
   AlignScratch scratch;
   // window staging (verify stage)
@@ -221,7 +231,18 @@ extern "C" int pm_add_pattern(pm_handle *h, const char *pat, size_t len, uint64_
   return PM_OK;
 }
 
+static void drain_spec(pm_handle *h);
+static void device_sort_plan(pm_handle *h);
+
 static void free_device(pm_handle *h) {
+  drain_spec(h);
+  if (h->land) (void)hipHostFree(h->land);
+  h->land = nullptr; h->land_cap = h->land_n = h->land_pos = 0;
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
+  h->copy_stream = nullptr; h->ev_fin = nullptr;
+  if (h->d_fsorted) (void)hipFree(h->d_fsorted);
+  h->d_fsorted = nullptr; h->fsorted_cap = 0;
   bitpar_free(&h->bp);
   seed_free(&h->sd);
   for (SeedDevice &d : h->sd_more) seed_free(&d);
@@ -417,6 +438,8 @@ static bool seed_eligible(pm_handle *h, std::string *why) {
 }
 
 static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
+  drain_spec(h);
+  h->land_n = h->land_pos = 0;
   if (table) {
     if (table_len <= 0 || table_len > 256) return fail(h, PM_E_INVALID, "bad alphabet table length");
     h->alpha.set_table(table, table_len);
@@ -644,11 +667,16 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   if (!h->h_seed_count) { HIP_TRY(h, hipHostMalloc((void **)&h->h_seed_count, (1 + 256) * sizeof(unsigned long long), hipHostMallocDefault)); memset(h->h_seed_count, 0, (1 + 256) * sizeof(unsigned long long)); }
   if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
   if (!h->ev1) HIP_TRY(h, hipEventCreate(&h->ev1));
+  if (!h->host_only) {
+    if (!h->ev_fin) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
+    if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  }
   if (!h->d_cands) { rc = ensure_capacity(h, (size_t)1 << 20); if (rc) return rc; }
   if (h->edits_dev && !h->host_only) {                              // every candidate is reported by several seeds before the dedup
     const size_t want = std::min<size_t>(std::max<size_t>((size_t)(h->n / 24), (size_t)1 << 22), (size_t)1 << 28);
     if (h->cap < want) { rc = ensure_capacity(h, want); if (rc) return rc; }
   }
+  device_sort_plan(h);
   h->inited = true;
   return pm_reset(h);
 }
@@ -777,15 +805,18 @@ extern "C" int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const
 extern "C" int pm_set_capacity(pm_handle *h, size_t max_candidates) {
   if (!h || max_candidates == 0) return PM_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  drain_spec(h);
   return ensure_capacity(h, max_candidates, true);
 }
 
 extern "C" int pm_reset(pm_handle *h) {
   if (!h) return PM_E_INVALID;
-  h->carry.clear(); h->ready.clear(); h->ready_pos = 0; h->next_begin = 0;
+  drain_spec(h);
+  if (h->scan_pending) { (void)hipStreamSynchronize(h->stream); h->scan_pending = false; }
+  h->carry.clear(); h->land_n = h->land_pos = 0; h->next_begin = 0;
   std::fill(h->lasthit.begin(), h->lasthit.end(), 0);
   h->halves_fresh = true;
-  h->last_count = 0; h->scan_pending = false;
+  h->last_count = 0;
   return PM_OK;
 }
 
@@ -836,6 +867,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
   if (begin < 0 || end < begin) return fail(h, PM_E_INVALID, "pm_scan_candidates: bad range");
   if (end > h->n) end = h->n;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  drain_spec(h);
   HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
   h->own_begin = begin; h->own_end = end;
@@ -1338,6 +1370,15 @@ extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   }
 }
 
+// The scan pm_scan enqueued for the range it expected next, and nobody asked for after all (another range, pm_reset,
+// a direct scan or finalize call, pm_destroy): let it finish and forget it.
+static void drain_spec(pm_handle *h) {
+  if (!h->spec) return;
+  h->spec = false;
+  if (h->scan_pending) { (void)hipStreamSynchronize(h->stream); h->scan_pending = false; }
+  h->last_count = 0;
+}
+
 extern "C" int pm_scan_candidates(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out) {
   int rc = pm_scan_candidates_async(h, begin, end);
   if (rc) return rc;
@@ -1438,12 +1479,15 @@ int fetch_windows(pm_handle *h, std::vector<Window> &wins) {
     }
     std::vector<int64_t> st(cnt), of(cnt); std::vector<int32_t> ln(cnt);
     for (size_t i = 0; i < cnt; ++i) { st[i] = wins[i].start; ln[i] = wins[i].len; of[i] = wins[i].off; }
-    HIP_TRY(h, hipMemcpyAsync(h->d_wstart, st.data(), cnt * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_wlen, ln.data(), cnt * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_woff, of.data(), cnt * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, gather_windows(h->d_text, h->n, h->d_wstart, h->d_wlen, h->d_woff, (int)cnt, h->d_wout, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->winbuf.data(), h->d_wout, (size_t)total, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, stream_wait(h));
+    // (while pm_scan has the next range's scan on the handle's stream, the windows go through the copy stream: the
+    // stream text is read-only and the staging buffers are used by this function alone)
+    hipStream_t ws = h->spec && h->copy_stream ? h->copy_stream : h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_wstart, st.data(), cnt * 8, hipMemcpyHostToDevice, ws));
+    HIP_TRY(h, hipMemcpyAsync(h->d_wlen, ln.data(), cnt * 4, hipMemcpyHostToDevice, ws));
+    HIP_TRY(h, hipMemcpyAsync(h->d_woff, of.data(), cnt * 8, hipMemcpyHostToDevice, ws));
+    HIP_TRY(h, gather_windows(h->d_text, h->n, h->d_wstart, h->d_wlen, h->d_woff, (int)cnt, h->d_wout, ws));
+    HIP_TRY(h, hipMemcpyAsync(h->winbuf.data(), h->d_wout, (size_t)total, hipMemcpyDeviceToHost, ws));
+    HIP_TRY(h, hipStreamSynchronize(ws));
   }
   for (int64_t i = 0; i < total; ++i) h->winbuf[i] = h->alpha.ch[h->winbuf[i]];
   return PM_OK;
@@ -1732,6 +1776,7 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
   switch (h->sem) {
     case PM_SEM_KEYWORD_TREE: case PM_SEM_SHIFT_AND: case PM_SEM_SHIFT_AND_INEXACT:
       outv.insert(outv.end(), cands, cands + n);
+      for (size_t i = outv.size() - n; i < outv.size(); ++i) outv[i].aux[0] = outv[i].aux[1] = outv[i].aux[2] = 0;   // engine-private bytes
       break;
     case PM_SEM_FILTER_BITVEC: rc = finalize_filter_bitvec(h, cands, n, scanned_to, last, outv); break;
     case PM_SEM_EXACT_HALVES:
@@ -1740,7 +1785,10 @@ static int finalize_into(pm_handle *h, const pm_hit *cands, size_t n, int64_t sc
          : h->halves_dev ? finalize_extended(h, cands, n, outv) : finalize_seeds(h, cands, n, true, outv);
       break;
     case PM_SEM_EXACT_BASES:
-      if (h->bases_flags) outv.insert(outv.end(), cands, cands + n);   // seed family: the records are the hits
+      if (h->bases_flags) {                                          // seed family: the records are the hits
+        outv.insert(outv.end(), cands, cands + n);
+        for (size_t i = outv.size() - n; i < outv.size(); ++i) outv[i].aux[0] = outv[i].aux[1] = outv[i].aux[2] = 0;
+      }
       else rc = finalize_seeds(h, cands, n, false, outv);
       break;
     default: return fail(h, PM_E_INVALID, "finalize: bad semantics");
@@ -1769,8 +1817,13 @@ extern "C" int pm_finalize(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
 // d_cands == NULL means "the records of the last pm_scan_candidates".  Final hits are copied to
 // `out` (host).  The few clusters the device cannot decide (still growing at scanned_to, or
 // starting inside the first L characters) go through the host stage.
+// `next` != NULL is pm_scan's form: the final hits are sorted on the device and land, in (end, pid, k) order, behind the
+// records the handle's landing buffer already holds; with next->on the scan of the range (next->b, next->e] is enqueued
+// behind the finalize kernels before the host waits for them, so that the copies out of HBM and everything the caller
+// does with the hits run beside it.
+struct ScanNext { bool on; int64_t b, e; };
 static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
-                                const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out);
+                                const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out, const ScanNext *next = nullptr);
 
 // filter_bitvec with -K and no exact-base constraints: its verify is "smallest level, left-most end"
 // (pm_cluster.hip), no stream text needed
@@ -1784,6 +1837,7 @@ static bool device_cluster_plain(const pm_handle *h) {
 extern "C" int pm_finalize_device(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
                                   pm_hit *out, size_t cap, size_t *n_out) {
   const OwnedRange all = {0, 0, 0, 0, 0};
+  if (h) drain_spec(h);
   return finalize_device_impl(h, d_cands, n, scanned_to, flags, all, out, cap, n_out);
 }
 
@@ -1799,13 +1853,112 @@ extern "C" int pm_finalize_device_owned(pm_handle *h, const void *d_cands, size_
     return fail(h, PM_E_INVALID, "pm_finalize_device_owned: need guard_lo <= own_lo <= own_hi <= guard_hi");
   // the shard that holds the true end of the stream also owns the hits that end beyond it (extensions that read
   // past the end, stream_end_overhang_candidates)
+  if (h) drain_spec(h);
   const bool to_the_end = h && guard_hi == INT64_MAX && own_hi >= h->n;
   const OwnedRange own = {own_lo, to_the_end ? INT64_MAX : own_hi, guard_lo, guard_hi, 1};
   return finalize_device_impl(h, d_cands, n, guard_hi == INT64_MAX ? h->n : guard_hi, flags | PM_FINALIZE_LAST, own, out, cap, n_out);
 }
 
+// room for `need` records in the landing buffer, the ones not handed out yet moved to its front
+static int ensure_landing(pm_handle *h, size_t need_more) {
+  const size_t live = h->land_n - h->land_pos;
+  if (h->land_cap >= live + need_more) {
+    if (h->land_pos) { if (live) memmove(h->land, h->land + h->land_pos, live * sizeof(pm_hit)); h->land_n = live; h->land_pos = 0; }
+    return PM_OK;
+  }
+  const size_t want = live + need_more;
+  const size_t cap = std::max<size_t>(want + want / 2, (size_t)1 << 16);
+  pm_hit *p = nullptr;
+  HIP_TRY(h, hipHostMalloc((void **)&p, cap * sizeof(pm_hit), hipHostMallocDefault));
+  if (live) memcpy(p, h->land + h->land_pos, live * sizeof(pm_hit));
+  if (h->land) (void)hipHostFree(h->land);
+  h->land = p; h->land_cap = cap; h->land_n = live; h->land_pos = 0;
+  return PM_OK;
+}
+
+// Can the device put final hits in (end, pid, k) order with one keys-only radix sort (pm_cluster.hip sort_final_device)?
+// key = end | pattern index | k in <= 63 bits, pattern ids growing with the index.  Decided once per init.
+static void device_sort_plan(pm_handle *h) {
+  h->sort_dev = false;
+  if (h->cfg.k > 3 || h->pats.empty() || h->pats.size() >= ((size_t)1 << 22)) return;
+  for (size_t i = 1; i < h->pats.size(); ++i) if (h->pats[i].id <= h->pats[i - 1].id) return;
+  int ib = 1, eb = 0;
+  while (((size_t)1 << ib) < h->pats.size()) ++ib;
+  const uint64_t maxend = (uint64_t)h->n + 512;                     // (extensions may end a few characters beyond the stream)
+  while (eb < 64 && (maxend >> eb)) ++eb;
+  h->sort_idxbits = ib; h->sort_keybits = eb + ib + 2;
+  h->sort_dev = h->sort_keybits <= 63;
+}
+
+// pattern lengths and ids by pattern index, on the device (clustering, the halves rule, the final sort)
+static int ensure_fpat(pm_handle *h) {
+  if (h->d_fpat_len) return PM_OK;
+  std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
+  for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
+  HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));
+  HIP_TRY(h, hipMalloc((void **)&h->d_fpat_id, pi.size() ? pi.size() * 4 : 4));
+  if (!pl.empty()) {
+    HIP_TRY(h, hipMemcpy(h->d_fpat_len, pl.data(), pl.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
+  }
+  return PM_OK;
+}
+
+// pm_scan's landing: n_upper bounds the number of final hits at d_hits (their count is d_count on the device when the
+// kernels in front produce it, else n_upper itself).  Enqueues the sort; *sorted tells whether the device could.
+static int land_enqueue_sort(pm_handle *h, const pm_hit *d_hits, const unsigned long long *d_count, size_t n_upper, bool *sorted) {
+  *sorted = false;
+  if (n_upper == 0 || n_upper > (size_t)INT_MAX / 2 || !h->sort_dev) return PM_OK;
+  { int rcw = ensure_sort_workspace(h, n_upper, false); if (rcw) return rcw; }
+  { int rcp = ensure_fpat(h); if (rcp) return rcp; }
+  if (h->fsorted_cap < n_upper) {
+    if (h->d_fsorted) (void)hipFree(h->d_fsorted);
+    h->d_fsorted = nullptr;
+    h->fsorted_cap = std::max<size_t>(n_upper + n_upper / 4, (size_t)1 << 16);
+    HIP_TRY(h, hipMalloc((void **)&h->d_fsorted, h->fsorted_cap * sizeof(pm_hit)));
+  }
+  HIP_TRY(h, sort_final_device(d_hits, d_count, n_upper, h->d_fpat_id, (uint32_t)h->pats.size(), h->sort_idxbits, h->sort_keybits,
+                               h->d_keys, h->d_keys_alt, h->d_fsorted, h->d_ctemp, h->ctemp_bytes, h->stream));
+  *sorted = true;
+  return PM_OK;
+}
+
+// Wait for the finalize kernels enqueued so far.  pm_scan's form (next): the scan of the next range goes in behind them first.
+static int finalize_sync(pm_handle *h, const ScanNext *next) {
+  if (!next) { HIP_TRY(h, stream_wait(h)); return PM_OK; }
+  HIP_TRY(h, hipEventRecord(h->ev_fin, h->stream));
+  if (next->on && !h->spec) {
+    if (pm_scan_candidates_async(h, next->b, next->e) == PM_OK) { h->spec = true; h->spec_b = next->b; h->spec_e = next->e; }
+  }
+  HIP_TRY(h, hipEventSynchronize(h->ev_fin));
+  return PM_OK;
+}
+
+// nfin final hits (sorted on the device: d_sorted, else as they are at d_hits) + the host-decided `extra` -> landing buffer,
+// in (end, pid, k) order.  The copy runs on the copy stream: the handle's stream may hold the next range's scan.
+static int land_collect(pm_handle *h, const pm_hit *d_hits, bool sorted, size_t nfin, std::vector<pm_hit> &extra, size_t *n_out) {
+  { int rcl = ensure_landing(h, nfin + extra.size()); if (rcl) return rcl; }
+  pm_hit *dst = h->land + h->land_n;
+  if (nfin) {
+    HIP_TRY(h, hipMemcpyAsync(dst, sorted ? h->d_fsorted : d_hits, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+    if (!sorted) {
+      for (size_t i = 0; i < nfin; ++i) dst[i].aux[0] = dst[i].aux[1] = dst[i].aux[2] = 0;
+      sort_hits(dst, nfin);
+    }
+  }
+  if (!extra.empty()) {
+    sort_hits(extra.data(), extra.size());
+    memcpy(dst + nfin, extra.data(), extra.size() * sizeof(pm_hit));
+    std::inplace_merge(dst, dst + nfin, dst + nfin + extra.size(), by_end_pid);
+  }
+  h->land_n += nfin + extra.size();
+  if (n_out) *n_out = nfin + extra.size();
+  return PM_OK;
+}
+
 static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int64_t scanned_to, int flags,
-                                const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out) {
+                                const OwnedRange &own, pm_hit *out, size_t cap, size_t *n_out, const ScanNext *next) {
   if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_finalize_device: handle not initialised");
   if (h->host_only) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this handle runs the host stage only (use pm_finalize)");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1814,7 +1967,8 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   const bool last = flags & PM_FINALIZE_LAST;
   if (n_out) *n_out = 0;
   // out == NULL: the final hits stay in HBM (pm_final_hits_device) for the exchange step of a sharded scan
-  const bool keep = out == nullptr;
+  const bool land = next != nullptr;
+  const bool keep = out == nullptr && !land;
   h->d_final = nullptr; h->n_final = 0;
   if (keep && (flags & PM_FINALIZE_SORTED)) return fail(h, PM_E_INVALID, "pm_finalize_device: PM_FINALIZE_SORTED needs a host buffer");
   const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT ||
@@ -1825,6 +1979,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   // exact_halves on the seed family: its per-pattern sequential rule as a sort + one walk per pattern
   // (pm_halves_rule).  Stateless, so only for a complete range on a fresh engine state.
   const bool halves = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && h->pats.size() < ((size_t)1 << 22) - 1;
+  std::vector<pm_hit> none;
   if (halves) {
     if (!last || own.on || !h->halves_fresh || !h->carry.empty())
       return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: exact_halves on the device needs the whole range in one call after pm_reset (use pm_finalize)");
@@ -1840,22 +1995,16 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
       h->htemp_bytes = halves_temp_bytes(h->vals_cap);
       HIP_TRY(h, hipMalloc(&h->d_htemp, h->htemp_bytes ? h->htemp_bytes : 16));
     }
-    if (!h->d_fpat_len) {
-      std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
-      for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
-      HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));
-      HIP_TRY(h, hipMalloc((void **)&h->d_fpat_id, pi.size() ? pi.size() * 4 : 4));
-      if (!pl.empty()) {
-        HIP_TRY(h, hipMemcpy(h->d_fpat_len, pl.data(), pl.size(), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
-      }
-    }
+    { int rcp = ensure_fpat(h); if (rcp) return rcp; }
     HIP_TRY(h, halves_rule_device(src, n, h->seed_flags, h->cfg.indels ? 2 * h->cfg.k : 0, h->d_fpat_len, h->d_fpat_id, h->d_keys, h->d_keys_alt,
                                   h->d_vals, h->d_vals_alt, h->d_htemp, h->htemp_bytes, h->d_fout, h->d_fcounts, h->stream));
+    bool sorted = false;
+    if (land) { int rcs = land_enqueue_sort(h, h->d_fout, h->d_fcounts, m, &sorted); if (rcs) return rcs; }
     HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, stream_wait(h));
+    { int rcy = finalize_sync(h, next); if (rcy) return rcy; }
     const size_t nfin = (size_t)h->h_fcounts[0];
     if (n_out) *n_out = nfin;
+    if (land) return land_collect(h, h->d_fout, sorted, nfin, none, n_out);
     if (keep) { h->d_final = h->d_fout; h->n_final = nfin; return PM_OK; }
     if (nfin > cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: out buffer too small");
     if (nfin) HIP_TRY(h, hipMemcpy(out, h->d_fout, nfin * sizeof(pm_hit), hipMemcpyDeviceToHost));
@@ -1863,6 +2012,12 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     return PM_OK;
   }
   if (!passthrough && !cluster) return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: this option set needs the host stage (pm_finalize)");
+  if (passthrough && land) {                                        // the records are the hits: sort, [next scan], copy
+    bool sorted = false;
+    { int rcs = land_enqueue_sort(h, src, nullptr, n, &sorted); if (rcs) return rcs; }
+    { int rcy = finalize_sync(h, next); if (rcy) return rcy; }
+    return land_collect(h, src, sorted, n, none, n_out);
+  }
   if (passthrough && keep) {
     if (own.on) {                                                   // the records that end in the owned range, compacted on the device
       { int rcw = ensure_sort_workspace(h, n, true); if (rcw) return rcw; }
@@ -1884,16 +2039,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     return PM_OK;
   }
   { int rcw = ensure_sort_workspace(h, n + h->carry.size(), true); if (rcw) return rcw; }
-  if (!h->d_fpat_len) {
-    std::vector<uint8_t> pl(h->pats.size()); std::vector<uint32_t> pi(h->pats.size());
-    for (size_t i = 0; i < h->pats.size(); ++i) { pl[i] = (uint8_t)std::min<size_t>(h->pats[i].s.size(), 255); pi[i] = (uint32_t)h->pats[i].id; }
-    HIP_TRY(h, hipMalloc((void **)&h->d_fpat_len, pl.size() ? pl.size() : 1));
-    HIP_TRY(h, hipMalloc((void **)&h->d_fpat_id, pi.size() ? pi.size() * 4 : 4));
-    if (!pl.empty()) {
-      HIP_TRY(h, hipMemcpy(h->d_fpat_len, pl.data(), pl.size(), hipMemcpyHostToDevice));
-      HIP_TRY(h, hipMemcpy(h->d_fpat_id, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
-    }
-  }
+  { int rcp = ensure_fpat(h); if (rcp) return rcp; }
   if (cluster_dp) { int rcd = ensure_dp_tables(h); if (rcd) return rcd; }
   // candidates an earlier range left undecided (clusters that could still grow) join this batch on
   // the device: their chains continue here
@@ -1918,9 +2064,11 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   else
   HIP_TRY(h, cluster_device(src, n, h->d_carry, ncarry, h->cfg.k, scanned_to, last, h->zoned ? 3 : -1, h->d_fpat_len, h->d_fpat_id, own, h->d_keys, h->d_keys_alt,
                             h->d_ctemp, h->ctemp_bytes, h->d_fout, h->d_fleft, h->d_fcounts, h->stream));
+  bool sorted = false;
+  if (land) { int rcs = land_enqueue_sort(h, h->d_fout, h->d_fcounts, n + ncarry, &sorted); if (rcs) return rcs; }
   h->h_fcounts[2] = 0;
-  HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, (n ? 3 : 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, stream_wait(h));
+  HIP_TRY(h, hipMemcpyAsync(h->h_fcounts, h->d_fcounts, ((n + ncarry) ? 3 : 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  { int rcy = finalize_sync(h, next); if (rcy) return rcy; }
   const size_t nfin = (size_t)h->h_fcounts[0], nleft = (size_t)h->h_fcounts[1];
   if (own.on && h->h_fcounts[2])
     return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device_owned: a chain of candidates reaches from the guard edge into the owned range (repeat longer than the guard band)");
@@ -1928,6 +2076,10 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
   if (nleft) {
     const size_t at = hostpart.size();
     hostpart.resize(at + nleft);
+    if (land) {                                                     // (the handle's stream may hold the next range's scan)
+      HIP_TRY(h, hipMemcpyAsync(hostpart.data() + at, h->d_fleft, nleft * sizeof(pm_hit), hipMemcpyDeviceToHost, h->copy_stream));
+      HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+    } else
     HIP_TRY(h, hipMemcpy(hostpart.data() + at, h->d_fleft, nleft * sizeof(pm_hit), hipMemcpyDeviceToHost));
   }
   std::vector<pm_hit> extra;
@@ -1935,6 +2087,12 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     int rc = finalize_into(h, hostpart.data(), hostpart.size(), scanned_to, last, extra);
     if (rc) return rc;
     if (own.on) extra.erase(std::remove_if(extra.begin(), extra.end(), [&](const pm_hit &x) { return !(x.end > own.own_lo && x.end <= own.own_hi); }), extra.end());
+  }
+  if (land) {
+    const int rcl = land_collect(h, h->d_fout, sorted, nfin, extra, n_out);
+    if (h->knobs.debug) fprintf(stderr, "[pm] finalize_device (pm_scan): %zu records, device %.1f ms (%zu finals, %zu left for the host), host part + copies %.1f ms%s\n",
+                                n, tfd1 - tfd0, nfin, nleft, now_ms() - tfd1, h->spec ? ", next range's scan in flight" : "");
+    return rcl;
   }
   if (keep) {                                                       // the few host-decided hits join the device's in HBM
     if (nfin + extra.size() > h->ckeys_cap) return fail(h, PM_E_OVERFLOW, "pm_finalize_device: device output buffer too small");
@@ -2053,50 +2211,71 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
   return PM_OK;
 }
 
+// One range of PatternMatch::find_patterns: scan, finalize, final hits in (end, pid, k) order behind whatever the landing
+// buffer still holds.  With a device finalize stage the scan of the range expected next -- the same number of stream
+// bytes, the way the reference's callers walk a stream chunk by chunk -- is already on the GPU when this returns.
+static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
+  if (begin != h->next_begin) return fail(h, PM_E_INVALID, "pm_scan: ranges must be consecutive (pm_reset to restart)");
+  size_t cnt = 0;
+  int rc;
+  if (h->spec && h->spec_b == begin && h->spec_e == end && h->scan_pending) { h->spec = false; rc = pm_scan_wait(h, &cnt); }
+  else rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);       // (drains a speculative scan of another range)
+  while (rc == PM_E_OVERFLOW && cnt > h->cap) {                     // grow and redo this range
+    rc = ensure_capacity(h, cnt + cnt / 4 + 1024);
+    if (rc) return rc;
+    rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
+  }
+  if (rc) return rc;
+  const bool halves_whole = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && begin == 0 && end >= h->n &&
+                            h->halves_fresh && h->carry.empty() && h->pats.size() < ((size_t)1 << 22) - 1;
+  const bool passthrough = h->sem == PM_SEM_KEYWORD_TREE || h->sem == PM_SEM_SHIFT_AND || h->sem == PM_SEM_SHIFT_AND_INEXACT ||
+                           (h->sem == PM_SEM_EXACT_BASES && h->bases_flags);
+  if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.wildcards && h->pats.size() < ((size_t)1 << 22)) || halves_whole ||
+      (device_cluster_plain(h) && h->kern == PM_KERNEL_SEED) || passthrough) {
+    // sort, clusters and their DPs on the device; only what it hands back goes through the host stage
+    ScanNext next = {end < h->n, end, std::min<int64_t>(h->n, end + (end - begin))};
+    const OwnedRange all = {0, 0, 0, 0, 0};
+    rc = finalize_device_impl(h, nullptr, 0, end, end >= h->n ? PM_FINALIZE_LAST : 0, all, nullptr, 0, nullptr, &next);
+    if (rc) return rc;
+  } else {
+    std::vector<pm_hit> cands(cnt), outv;
+    if (cnt) HIP_TRY(h, hipMemcpy(cands.data(), h->d_cands, cnt * sizeof(pm_hit), hipMemcpyDeviceToHost));
+    rc = finalize_into(h, cands.data(), cnt, end, end >= h->n, outv);
+    if (rc) return rc;
+    sort_hits(outv.data(), outv.size());
+    rc = ensure_landing(h, outv.size());
+    if (rc) return rc;
+    if (!outv.empty()) memcpy(h->land + h->land_n, outv.data(), outv.size() * sizeof(pm_hit));
+    h->land_n += outv.size();
+  }
+  h->next_begin = end;
+  return PM_OK;
+}
+
 extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more) {
   if (!h || !h->inited) return fail(h, PM_E_INVALID, "pm_scan: handle not initialised");
   if (n_out) *n_out = 0;
   if (more) *more = 0;
   if (end > h->n) end = h->n;
-  if (end > begin) {
-    if (begin != h->next_begin) return fail(h, PM_E_INVALID, "pm_scan: ranges must be consecutive (pm_reset to restart)");
-    std::vector<pm_hit> cands;
-    size_t cnt = 0;
-    int rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
-    while (rc == PM_E_OVERFLOW && cnt > h->cap) {                     // grow and redo this range
-      rc = ensure_capacity(h, cnt + cnt / 4 + 1024);
-      if (rc) return rc;
-      rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
-    }
-    if (rc) return rc;
-    std::vector<pm_hit> outv;
-    const bool halves_whole = h->sem == PM_SEM_EXACT_HALVES && (h->seed_flags || h->halves_dev) && begin == 0 && end >= h->n &&
-                              h->halves_fresh && h->carry.empty() && h->pats.size() < ((size_t)1 << 22) - 1;
-    if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.wildcards && h->pats.size() < ((size_t)1 << 22)) || halves_whole ||
-        (device_cluster_plain(h) && h->kern == PM_KERNEL_SEED)) {
-      // clusters and their DPs on the device (pm_cluster_dp); only what it hands back goes through the host stage
-      outv.resize((h->seed_flags ? 2 * cnt : cnt) + h->carry.size() + 16);
-      size_t nout = 0;
-      rc = pm_finalize_device(h, nullptr, 0, end, end >= h->n ? PM_FINALIZE_LAST : 0, outv.data(), outv.size(), &nout);
-      if (rc) return rc;
-      outv.resize(nout);
-    } else {
-      cands.resize(cnt);
-      if (cnt) HIP_TRY(h, hipMemcpy(cands.data(), h->d_cands, cnt * sizeof(pm_hit), hipMemcpyDeviceToHost));
-      rc = finalize_into(h, cands.data(), cnt, end, end >= h->n, outv);
-      if (rc) return rc;
-    }
-    sort_hits(outv.data(), outv.size());
-    if (h->ready_pos == h->ready.size()) { h->ready.clear(); h->ready_pos = 0; }
-    h->ready.insert(h->ready.end(), outv.begin(), outv.end());
-    h->next_begin = end;
-  }
-  size_t avail = h->ready.size() - h->ready_pos;
-  size_t take = std::min(avail, cap);
-  if (take && out) memcpy(out, h->ready.data() + h->ready_pos, take * sizeof(pm_hit));
-  else take = out ? take : 0;
-  h->ready_pos += take;
+  if (end > begin) { const int rc = scan_range(h, begin, end); if (rc) return rc; }
+  const size_t avail = h->land_n - h->land_pos;
+  const size_t take = out ? std::min(avail, cap) : 0;
+  if (take) memcpy(out, h->land + h->land_pos, take * sizeof(pm_hit));
+  h->land_pos += take;
+  if (h->land_pos == h->land_n) h->land_pos = h->land_n = 0;
   if (n_out) *n_out = take;
-  if (more) *more = h->ready_pos < h->ready.size();
+  if (more) *more = h->land_pos < h->land_n;
+  return PM_OK;
+}
+
+extern "C" int pm_scan_view(pm_handle *h, int64_t begin, int64_t end, const pm_hit **hits, size_t *n) {
+  if (!h || !h->inited || !hits || !n) return fail(h, PM_E_INVALID, "pm_scan_view: bad arguments");
+  *hits = nullptr; *n = 0;
+  if (end > h->n) end = h->n;
+  if (h->land_pos == h->land_n) h->land_pos = h->land_n = 0;       // the span of the last call is given up
+  if (end > begin) { const int rc = scan_range(h, begin, end); if (rc) return rc; }
+  *hits = h->land + h->land_pos;
+  *n = h->land_n - h->land_pos;
+  h->land_pos = h->land_n;                                          // handed out; the memory stays valid until the next call
   return PM_OK;
 }

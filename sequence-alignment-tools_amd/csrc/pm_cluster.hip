@@ -459,6 +459,61 @@ hipError_t owned_filter_device(const pm_hit *d_in, size_t n, const OwnedRange &o
   return hipGetLastError();
 }
 
+// ---- final hits in (end, pid, k) order (pm_scan: PatternMatch::find_patterns hands its hits out in stream order,
+// primer_match.cc:1118-1121; the reference's callers sort by key, sortedvector.t:490-510) -------------------------
+// A final hit is (end, pattern, k) and nothing else, so the whole record fits the sort key: end | pattern index | k,
+// a keys-only radix sort (a pass over 16-byte values costs three times a keys-only pass at 10^5 records) and one kernel
+// that turns keys back into records.  Needs pattern ids that grow with the pattern index (the reference's callers add
+// ids 1..N in order, primer_match.cc:1105-1107): index order is then id order, and the index of an id is found by
+// bisection in the id table.  The number of records may be known only on the device (*d_count, written by the kernel in
+// front on the same stream): the sort then runs over the host's upper bound, the slots beyond *d_count get a key above
+// every real one and stay behind the real records.
+namespace {
+__global__ void pm_final_pack(const pm_hit *in, const unsigned long long *d_count, size_t n_upper, const uint32_t *pat_id, uint32_t npat,
+                              int idxbits, int keybits, uint64_t *keys) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n_upper) return;
+  const size_t n = d_count ? (size_t)*d_count : n_upper;
+  uint64_t key = 1ull << keybits;                                   // padding: above every real key
+  if (i < n) {
+    const pm_hit h = in[i];
+    uint32_t lo = 0, hi = npat;                                     // first index with pat_id[index] >= h.pid
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pat_id[mid] < h.pid) lo = mid + 1; else hi = mid; }
+    key = ((uint64_t)h.end << (idxbits + 2)) | ((uint64_t)lo << 2) | (uint64_t)(h.k & 3u);
+  }
+  keys[i] = key;
+}
+
+__global__ void pm_final_unpack(const uint64_t *keys, const unsigned long long *d_count, size_t n_upper, const uint32_t *pat_id, int idxbits, pm_hit *out) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t n = d_count ? (size_t)*d_count : n_upper;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  pm_hit h;
+  h.end = (int64_t)(key >> (idxbits + 2));
+  h.pid = pat_id[(uint32_t)(key >> 2) & ((1u << idxbits) - 1u)];
+  h.k = (uint8_t)(key & 3u);
+  h.aux[0] = h.aux[1] = h.aux[2] = 0;                               // engine-private bytes of candidate records do not leave
+  out[i] = h;
+}
+}  // namespace
+
+// keybits = bits of the largest end + idxbits + 2 (<= 63: the caller checks); the sort's temporary storage is that of
+// cluster_temp_bytes(n_upper)
+hipError_t sort_final_device(const pm_hit *d_in, const unsigned long long *d_count, size_t n_upper, const uint32_t *d_pat_id, uint32_t npat,
+                             int idxbits, int keybits, uint64_t *d_keys, uint64_t *d_keys_alt, pm_hit *d_out, void *d_temp, size_t temp_bytes, hipStream_t st) {
+  if (n_upper == 0) return hipSuccess;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((n_upper + threads - 1) / threads);
+  hipLaunchKernelGGL(pm_final_pack, dim3(blocks), dim3(threads), 0, st, d_in, d_count, n_upper, d_pat_id, npat, idxbits, keybits, d_keys);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int top = d_count ? keybits + 1 : keybits;                  // (the padding key has bit `keybits` set)
+  if ((e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys_alt, (int)n_upper, 0, top, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(pm_final_unpack, dim3(blocks), dim3(threads), 0, st, d_keys_alt, d_count, n_upper, d_pat_id, idxbits, d_out);
+  return hipGetLastError();
+}
+
 size_t cluster_temp_bytes(size_t n) {
   size_t bytes = 0;
   uint64_t *p = nullptr;

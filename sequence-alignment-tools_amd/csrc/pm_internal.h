@@ -113,6 +113,10 @@ hipError_t cluster_device(const pm_hit *d_in, size_t n1, const pm_hit *d_in2, si
                           pm_hit *d_out, pm_hit *d_left, unsigned long long *d_counts, hipStream_t st);
 
 
+// final hits in (end, pid, k) order on the device (pm_cluster.hip): see sort_final_device
+hipError_t sort_final_device(const pm_hit *d_in, const unsigned long long *d_count, size_t n_upper, const uint32_t *d_pat_id, uint32_t npat,
+                             int idxbits, int keybits, uint64_t *d_keys, uint64_t *d_keys_alt, pm_hit *d_out, void *d_temp, size_t temp_bytes, hipStream_t st);
+
 // records of d_in that end in the owned range, compacted into d_out (pass-through engines, sharded scans)
 hipError_t owned_filter_device(const pm_hit *d_in, size_t n, const OwnedRange &own, pm_hit *d_out, unsigned long long *d_count, hipStream_t st);
 

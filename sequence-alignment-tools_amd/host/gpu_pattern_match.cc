@@ -200,20 +200,16 @@ bool GpuPatternMatch::find_patterns(CharacterProducer &cp, pattern_hit_vector &h
   if (group_) return sharded_done_ ? false : sharded_scan(cp, hits);
   if (cp.eof()) return false;
   unsigned long got = 0;
-  std::vector<pm_hit> buf((size_t)1 << 16);
   while (true) {
     const int64_t begin = cp.pos();
     const int64_t end = begin + chunk_ < n_ ? begin + chunk_ : n_;
+    const pm_hit *recs = nullptr;
     size_t cnt = 0;
-    int more = 0;
-    if (pm_scan(h_, begin, end, buf.data(), buf.size(), &cnt, &more) != PM_OK) fatal("find_patterns");
+    // the records stay in the library's buffer; the GPU already scans the next range while they are pushed
+    if (pm_scan_view(h_, begin, end, &recs, &cnt) != PM_OK) fatal("find_patterns");
     cp.pos(end);
-    for (;;) {
-      for (size_t i = 0; i < cnt; ++i) hits.push_back(pattern_hit{buf[i].end, buf[i].pid, buf[i].k});
-      got += cnt;
-      if (!more) break;
-      if (pm_scan(h_, end, end, buf.data(), buf.size(), &cnt, &more) != PM_OK) fatal("find_patterns");
-    }
+    for (size_t i = 0; i < cnt; ++i) hits.push_back(pattern_hit{recs[i].end, recs[i].pid, recs[i].k});
+    got += cnt;
     if (got >= minka || cp.eof()) return got > 0;
   }
 }

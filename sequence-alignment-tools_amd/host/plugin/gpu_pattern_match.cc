@@ -7,7 +7,7 @@
 #include "util.h"            // reference: timestamp()
 
 gpu_pattern_match::gpu_pattern_match(int kernel, unsigned int k, char eos, bool wc, bool tn, bool indels, bool dna_mut)
-    : h_(0), buf_((size_t)1 << 16), n_(0), base_(0), chunk_((FILE_POSITION_TYPE)1 << 30) {
+    : h_(0), n_(0), base_(0), chunk_((FILE_POSITION_TYPE)1 << 28) {
   if (dna_mut) {
     timestamp("Fatal error: DNA mutation scoring is not available in the GPU engine.");
     exit(1);
@@ -73,24 +73,23 @@ bool gpu_pattern_match::find_patterns(CharacterProducer &cp, pattern_hit_vector 
   // The reference's callers loop `while (find_patterns(...) || !l.empty())` and read cp.pos() right
   // after the call as "scanned up to here" (primer_match.cc:1118-1121, pcr_match.cc:952,1057): every
   // hit returned ends at or before cp.pos(), hits arrive in non-decreasing end order.
+  // One range of chunk_ stream bytes per pm_scan_view call (256 MiB unless PM_GPU_CHUNK says otherwise: a first hit
+  // after ~1 ms of scanning, a dozen progress reports per 3 Gbp); the records are pushed straight from the library's
+  // buffer, and while they are the GPU already scans the next range (include/pm_gpu.h, pm_scan_view).
   long unsigned got = 0;
   for (;;) {
     const FILE_POSITION_TYPE begin = cp.pos() - base_;
     if (begin >= n_) return got > 0;
     const FILE_POSITION_TYPE end = begin + chunk_ < n_ ? begin + chunk_ : n_;
+    const pm_hit *recs = 0;
     size_t cnt = 0;
-    int more = 0;
-    if (pm_scan(h_, (int64_t)begin, (int64_t)end, &buf_[0], buf_.size(), &cnt, &more) != PM_OK) fatal("find_patterns");
+    if (pm_scan_view(h_, (int64_t)begin, (int64_t)end, &recs, &cnt) != PM_OK) fatal("find_patterns");
     cp.pos(end + base_);
-    for (;;) {
-      for (size_t i = 0; i < cnt; ++i) {
-        const pm_hit &r = buf_[i];
-        pas.push_back((FILE_POSITION_TYPE)r.end + base_, std::make_pair(by_id_[r.pid], (unsigned char)r.k));
-      }
-      got += cnt;
-      if (!more) break;
-      if (pm_scan(h_, (int64_t)end, (int64_t)end, &buf_[0], buf_.size(), &cnt, &more) != PM_OK) fatal("find_patterns");
+    for (size_t i = 0; i < cnt; ++i) {
+      const pm_hit &r = recs[i];
+      pas.push_back((FILE_POSITION_TYPE)r.end + base_, std::make_pair(by_id_[r.pid], (unsigned char)r.k));
     }
+    got += cnt;
     report_progress(cp);
     if (got >= minka) return true;
   }

@@ -34,7 +34,6 @@ class gpu_pattern_match : public PatternMatch {
   pm_handle *h_;
   std::vector<pattern_list::const_iterator> by_id_;   // id -> list element, for value.first of a hit
   std::vector<unsigned char> drained_;                // stream bytes of a producer without c_str()
-  std::vector<pm_hit> buf_;
   FILE_POSITION_TYPE n_;                              // stream bytes
   FILE_POSITION_TYPE base_;                           // cp.pos() of stream byte 0 (fasta_io.t:234-235 offset_)
   FILE_POSITION_TYPE chunk_;

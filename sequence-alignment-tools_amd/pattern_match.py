@@ -18,7 +18,7 @@ PM_E_OVERFLOW = -5
 
 # every entry point include/pm_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_candidates",
+    "pm_create", "pm_add_pattern", "pm_init", "pm_init_device", "pm_scan", "pm_scan_view", "pm_scan_candidates",
     "pm_scan_candidates_async", "pm_scan_wait", "pm_candidates_device", "pm_set_capacity", "pm_finalize",
     "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
@@ -78,6 +78,7 @@ def load_library():
         L.pm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
         L.pm_init_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.pm_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.pm_scan_view.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.pm_scan_candidates.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.pm_scan_candidates_async.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         L.pm_scan_wait.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
@@ -230,6 +231,21 @@ class PatternMatch:
             a = np.array(hits, dtype=np.int64)
             out["end"], out["pid"], out["k"] = a[:, 0], a[:, 1], a[:, 2]
         return out
+
+    def scan(self, begin, end, out):
+        """pm_scan itself (PatternMatch::find_patterns over [begin,end), pattern_match.h:131): final hits, sorted by
+        (end, pid), into the caller's array `out`; returns (count, more).  more: call again with begin == end."""
+        n_out, more = C.c_size_t(), C.c_int()
+        self._check(self._L.pm_scan(self._h, begin, end, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out), C.byref(more)))
+        return n_out.value, more.value
+
+    def scan_view(self, begin, end):
+        """pm_scan_view: the range's final hits as a numpy view of the handle's own buffer (valid until the next call)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.pm_scan_view(self._h, begin, end, C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value * 16,)).view(HIT_DTYPE)
 
     def pos(self):
         return self._pos

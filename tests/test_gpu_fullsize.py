@@ -347,3 +347,68 @@ def test_stream_beyond_two_to_the_32_with_default_chunks():
     total = sum(pm.scan_candidates(cuts[i], cuts[i + 1], to_host=False) for i in range(3))
     assert total == whole.size
     pm.close()
+
+
+# ---- pm_scan (PatternMatch::find_patterns, pattern_match.h:131) = scan_candidates + finalize_device, sorted -----------
+def _scan_all(pm, n, chunk, cap=None, view=False, lengths=None):
+    """the whole stream through pm_scan / pm_scan_view in consecutive ranges; returns the concatenated records"""
+    pm.reset()
+    parts, pos, i = [], 0, 0
+    buf = np.zeros(cap or 1, dtype=sat_amd.HIT_DTYPE)
+    while pos < n:
+        step = lengths[i % len(lengths)] if lengths else chunk
+        end = min(n, pos + step)
+        if view:
+            parts.append(pm.scan_view(pos, end).copy())
+        else:
+            cnt, more = pm.scan(pos, end, buf)
+            parts.append(buf[:cnt].copy())
+            while more:
+                cnt, more = pm.scan(end, end, buf)
+                parts.append(buf[:cnt].copy())
+        pos, i = end, i + 1
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=sat_amd.HIT_DTYPE)
+
+
+@pytest.mark.parametrize("k,indels", [(2, False), (2, True), (0, False), (1, False), (1, True)])
+def test_pm_scan_equals_candidates_plus_device_finalize_one_gbp(k, indels):
+    """the reference-facing call must give what the benchmarked step gives -- the same hits, in
+    (end, pid, k) order -- whatever the ranges: one call, the plugin's 256 MiB ranges through the zero-copy view,
+    ranges of changing length (every guess of the pipelined next scan wrong) drained 70,000 records at a time."""
+    n = (1 << 30) if not indels or k < 2 else (1 << 28)
+    L, P = 20, 100_000 if not (indels and k == 2) else 20_000
+    dev = make_db(n, 77 + k)
+    host = dev[: 1 << 24].cpu().numpy()
+    rng = np.random.default_rng(900 + 10 * k + int(indels))
+    plant = [x for d in range(k + 1) for x in planted(host, rng, 200, L, d)]
+    pats = [p for p, _, _ in plant] + ["".join("ACGT"[c] for c in rng.integers(0, 4, L)) for _ in range(P - len(plant))]
+    allp = pats + [sat_amd.reverse_comp(p) for p in pats]
+    pm = engine(allp, k, sat_amd.KERNEL_AUTO, dev, indels=indels)
+    pm.set_capacity(1 << 24 if not (indels and k == 2) else 1 << 26)
+    ncand = pm.scan_candidates(0, n, to_host=False)
+    try:
+        want = pm.finalize_device(n, last=True, sort=True, out=np.zeros(2 * ncand + 1024, dtype=sat_amd.HIT_DTYPE))
+    except sat_amd.PmError as e:                                    # exact_halves in chunks etc.: the host stage
+        assert e.code == -2
+        pm.reset()
+        want = pm.finalize(pm.copy_records(*pm.candidates_device()), n, last=True, sort=True)
+    want = want.copy()
+    assert want.size >= 200 and ncand >= want.size // 2
+    order = np.lexsort((want["k"], want["pid"], want["end"]))
+    assert (order == np.arange(want.size)).all()
+
+    def same(got, what):
+        assert got.size == want.size, (what, got.size, want.size)
+        for f in ("end", "pid", "k"):
+            assert (got[f] == want[f]).all(), (what, f)
+        assert not got["aux"].any(), what
+
+    same(_scan_all(pm, n, n, cap=1 << 24), "one call")
+    same(_scan_all(pm, n, 1 << 28, view=True), "256 MiB ranges, view")
+    same(_scan_all(pm, n, 1 << 28, view=True), "again (pm_reset in between)")
+    same(_scan_all(pm, n, 0, cap=70_000, lengths=[(1 << 27) + 12345, (1 << 26) - 7, 1 << 28]), "ragged ranges, small buffer")
+    # a scan nobody consumes, then direct stage calls on the same handle
+    pm.reset()
+    pm.scan_view(0, 1 << 26)
+    assert pm.scan_candidates(0, n, to_host=False) == ncand
+    pm.close()
