@@ -40,17 +40,60 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 32-bit integer lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 
 
-def gen_stream(lo, hi, total, entries, seed, device):
-    """Codes of global stream range [lo,hi): uniform A/C/G/T with an EOS at index 0 and after each
-    of `entries` equal-length entries (layout of compress_seq's .sqn)."""
+STYLES = ("uniform", "skew", "vocab", "tandem")
+
+
+def gen_block(b, seed, device, style):
+    """block b (BLOCK bases) of the global stream.  uniform: i.i.d. A/C/G/T (BASELINE.json's synthetic database).  The other
+    three are the generators of tests/adversarial.py (what scripts/fuzz_families.py found seven parity bugs with) at
+    database size, with the parameters at the hard end that still give an output a host can take:
+    skew   = i.i.d. with composition A .40 C .10 G .10 T .40;
+    vocab  = words of one vocabulary of 200 twelve-base words (the same for every block), 2 % point mutations;
+    tandem = tandem repeats: units of 1..39 random bases, 1..399 copies each, 3 % of the bases drifted."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 1000003 + b)
+    if style == "uniform":
+        return torch.randint(0, 4, (BLOCK,), dtype=torch.uint8, device=device, generator=g)
+    if style == "skew":
+        u = torch.rand(BLOCK, device=device, generator=g)
+        edges = torch.tensor([0.40, 0.50, 0.60], device=device)
+        return torch.bucketize(u, edges).to(torch.uint8)
+    if style == "vocab":
+        gv = torch.Generator(device=device)
+        gv.manual_seed(seed * 7919 + 17)
+        wl, nv = 12, 200
+        vocab = torch.randint(0, 4, (nv, wl), dtype=torch.uint8, device=device, generator=gv)
+        idx = torch.randint(0, nv, (BLOCK // wl + 1,), device=device, generator=g)
+        blk = vocab[idx].reshape(-1)[:BLOCK].clone()
+    else:                                                          # tandem
+        nseg = BLOCK // 20 + 64                                    # more segments than the block can hold (>= 1 base each)
+        ulen = torch.randint(1, 40, (nseg,), device=device, generator=g)
+        reps = torch.randint(1, 400, (nseg,), device=device, generator=g)
+        ends = torch.cumsum(ulen * reps, 0)
+        units = torch.randint(0, 4, (nseg, 40), dtype=torch.uint8, device=device, generator=g)
+        pos = torch.arange(BLOCK, device=device)
+        seg = torch.searchsorted(ends, pos, right=True)
+        start = torch.where(seg > 0, ends[(seg - 1).clamp(min=0)], torch.zeros_like(pos))
+        blk = units[seg, (pos - start) % ulen[seg]]
+    m = torch.rand(BLOCK, device=device, generator=g) < (0.02 if style == "vocab" else 0.03)
+    blk[m] = torch.randint(0, 4, (int(m.sum().item()),), dtype=torch.uint8, device=device, generator=g)
+    return blk
+
+
+def gen_stream(lo, hi, total, entries, seed, device, style="uniform", run=None):
+    """Codes of global stream range [lo,hi): A/C/G/T of the given style with an EOS at index 0 and after each of
+    `entries` equal-length entries (layout of compress_seq's .sqn).  run = (start, length): that many A's from `start`
+    on (a homopolymer run -- a centromeric satellite in the small -- for the cut-chain test of the sharded step)."""
     out = torch.empty(hi - lo, dtype=torch.uint8, device=device)
     b0, b1 = lo // BLOCK, (hi - 1) // BLOCK
     for b in range(b0, b1 + 1):
-        g = torch.Generator(device=device)
-        g.manual_seed(seed * 1000003 + b)
-        blk = torch.randint(0, 4, (BLOCK,), dtype=torch.uint8, device=device, generator=g)
+        blk = gen_block(b, seed, device, style)
         s, e = max(lo, b * BLOCK), min(hi, (b + 1) * BLOCK)
         out[s - lo:e - lo] = blk[s - b * BLOCK:e - b * BLOCK]
+    if run:
+        a, z = max(lo, run[0]), min(hi, run[0] + run[1])
+        if z > a:
+            out[a - lo:z - lo] = 0
     elen = (total - 1) // entries
     eos_pos = torch.arange(0, entries + 1, device=device, dtype=torch.int64) * elen
     eos_pos[-1] = total - 1
@@ -59,14 +102,14 @@ def gen_stream(lo, hi, total, entries, seed, device):
     return out
 
 
-def make_primers(stream0, n_primers, L, seed):
+def make_primers(stream0, n_primers, L, seed, from_stream=0.1):
     """90 % i.i.d. random 20-mers, 10 % sampled from the database and given 0/1/2 substitutions
-    (SURVEY 8d).  Returns (list of str, planted) with planted = [(primer index, stream index of the
+    (SURVEY 8d); from_stream = 1.0: every primer cut from the database (the hard streams of --stream-style).  Returns (list of str, planted) with planted = [(primer index, stream index of the
     site's first base, Hamming distance of the primer to the site)]."""
     rng = np.random.default_rng(seed)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     pri = rng.integers(0, 4, size=(n_primers, L), dtype=np.uint8)
-    n_pl = n_primers // 10
+    n_pl = int(n_primers * from_stream)
     host = stream0.cpu().numpy()
     placed = 0
     planted = []
@@ -208,18 +251,49 @@ def baseline_metric():
         return "Gbases/s scanned, 100k\u00d720-mer primers k\u22642, 3 Gbp DB at 1/2/4/8 GPUs"
 
 
-def measured_traffic(args, shard):
-    """HBM/fabric bytes per launch of the scan kernel from the committed PMC passes
-    (profiles/traffic_r*.json, produced by scripts/profile_round.sh), or None when this exact
-    workload was not profiled."""
+def code_sha():
+    """sha256 over the product's kernel and library sources (csrc/*.hip, *.cpp, *.h): what a counter file was collected on.
+    The GPU box has no .git, so this -- not the commit -- is what bench.py can compare at run time; scripts/collect_profiles.py
+    adds the commit (`head`) when it copies the counters into profiles/."""
     import glob
-    best = (None, None)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sequence-alignment-tools_amd", "csrc", "*.*"))):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_entry(pattern, args, shard):
+    """the newest committed counter entry (profiles/<pattern>) of this exact workload, with the file it came from"""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         with open(f) as fh:
             for e in json.load(fh).get("entries", []):
-                if (e["k"], e["indels"], e["db_bases"], e["primers"]) == (args.k, args.indels, shard, args.primers):
-                    best = (e["traffic_bytes"], "profiles/" + os.path.basename(f))
+                if (e["k"], e["indels"], e["db_bases"], e["primers"]) == (args.k, args.indels, shard, args.primers) and \
+                        e.get("stream_style", "uniform") == args.stream_style:
+                    best = (e, "profiles/" + os.path.basename(f))
     return best
+
+
+def staleness(e, kms):
+    """Were these counters collected on the code that runs now, and does the kernel still take what it took then?"""
+    sha = code_sha()
+    at = e.get("kernel_ms_at_profile")
+    drift = None if not at or not (kms > 0) else abs(kms - at) / at
+    return {"head": e.get("head"), "code_sha_at_profile": e.get("code_sha"), "code_sha_now": sha, "kernel_ms_at_profile": at,
+            "stale": bool(e.get("code_sha") != sha or drift is None or drift > 0.10)}
+
+
+def measured_traffic(args, shard):
+    """HBM/fabric bytes per launch of the scan kernel from the committed PMC passes
+    (profiles/traffic_r*.json, produced by scripts/pmc_traffic.sh), or None when this exact
+    workload was not profiled."""
+    best = profiled_entry("traffic_r*.json", args, shard)
+    return (None, None, None) if best is None else (best[0]["traffic_bytes"], best[1], best[0])
 
 
 def issue_roofline(args, shard, kms):
@@ -235,13 +309,7 @@ def issue_roofline(args, shard, kms):
       lds   = LDS-array active cycles (incl. bank conflicts), summed over the CUs / (256 x kernel cycles)
       l1_l2 = L1 -> L2 read requests (one 128-byte line each) x 2 cycles / (256 CUs x kernel cycles): the L2 -> L1
               return path moves 64 B per clock and CU (269 G lines/s for the chip, profiles/r03_probe_tcp_gather.txt)."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "issue_r*.json"))):
-        with open(f) as fh:
-            for e in json.load(fh).get("entries", []):
-                if (e["k"], e["indels"], e["db_bases"], e["primers"]) == (args.k, args.indels, shard, args.primers):
-                    best = (e, "profiles/" + os.path.basename(f))
+    best = profiled_entry("issue_r*.json", args, shard)
     if best is None or not (kms > 0):
         return None
     e, src = best
@@ -263,6 +331,7 @@ def issue_roofline(args, shard, kms):
         fr["l1_l2"] = out["l1_l2"]["frac"]
     if fr:
         out["binding"] = max(fr, key=fr.get)
+    out.update(staleness(e, kms))
     return out
 
 
@@ -286,6 +355,11 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the all-cores figure (0 = every host core)")
     ap.add_argument("--no-check", action="store_true", help="do not require the planted primer sites in the result (kernel stage measurements with PM_SEED_DEBUG)")
     ap.add_argument("--dump-hits", default="", help="rank 0 writes the final hits of the last step (global stream indices, sorted) to this .npy file")
+    ap.add_argument("--stream-style", choices=list(STYLES), default="uniform", help="composition of the synthetic stream (gen_block)")
+    ap.add_argument("--primer-source", choices=["auto", "mixed", "stream"], default="auto",
+                    help="mixed: 10 %% of the primers cut from the stream (SURVEY 8d); stream: all of them; auto: mixed on the uniform stream, stream on the others")
+    ap.add_argument("--pair-stats", action="store_true", help="count blocks, rounds and key hits in the pair kernel (PM_SEED_DEBUG bit 5; a measurement build of the same kernel)")
+    ap.add_argument("--plant-run", type=int, default=0, help="A x this many across the middle of the stream, and the primer A x length with it")
     ap.add_argument("--scan-passes", type=int, default=3, help="timed whole-stream passes through pm_scan itself after the timed region (0 = skip; single GPU only)")
     ap.add_argument("--scan-chunk", type=int, default=1 << 28, help="stream bytes per pm_scan range (the compiled plugin default)")
     ap.add_argument("--scan-cap", type=int, default=1 << 20, help="records the caller takes per pm_scan call")
@@ -325,13 +399,19 @@ def main():
     # the windows / seed extensions of the outermost candidates read
     glo = max(0, lo - GUARD - HALO)
     ghi = min(total, hi + GUARD + HALO)
-    stream = gen_stream(glo, ghi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev)
+    run = None
+    if args.plant_run > 0:                                          # a homopolymer run across the middle of the stream (= a shard edge of 2, 4, 8 ranks)
+        run = (total // 2 - args.plant_run // 2, args.plant_run)
+    stream = gen_stream(glo, ghi, total, args.entries * (world if args.scaling == "weak" else 1), 20260101, dev, args.stream_style, run)
     n_bases_total = total - (args.entries * (world if args.scaling == "weak" else 1) + 1)
     planted = []
     if rank == 0:
         # sampled from a prefix every launch geometry holds on rank 0 (so that 1 and N ranks of a
         # --scaling strong run search the same primers)
-        primers, planted = make_primers(stream[:min(stream.numel(), 1 << 26, max(total // 8, 1 << 16))], args.primers, args.length, 7)
+        src = {"mixed": 0.1, "stream": 1.0, "auto": 0.1 if args.stream_style == "uniform" else 1.0}[args.primer_source]
+        primers, planted = make_primers(stream[:min(stream.numel(), 1 << 26, max(total // 8, 1 << 16))], args.primers, args.length, 7, src)
+        if args.plant_run > 0:
+            primers[-1] = "A" * args.length                          # its candidates chain along the whole run
     else:
         primers = None
     if use_dist:
@@ -342,6 +422,8 @@ def main():
         primers = [p[:len(p) // 2] + "N" + p[len(p) // 2 + 1:] if i < args.odd else p for i, p in enumerate(primers)]
     allp = primers + [sat_amd.reverse_comp(p) for p in primers]
     kern = {"auto": sat_amd.KERNEL_AUTO, "bitpar": sat_amd.KERNEL_BITPAR, "seed": sat_amd.KERNEL_SEED}[args.kernel]
+    if args.pair_stats:                                             # the library reads its measurement knobs once, in pm_create
+        os.environ["PM_SEED_DEBUG"] = str(int(os.environ.get("PM_SEED_DEBUG", "0")) | 32)
     pm = sat_amd.PatternMatch(k=args.k, indels=bool(args.indels), kernel=kern, device=local)
     for i, p in enumerate(allp):
         pm.add_pattern(p, i + 1)
@@ -363,6 +445,7 @@ def main():
     final_hits = [0]
     cand_count = [0]
     rescans = [0]
+    cut_steps = [0]                                                 # steps that fell back to the gather-candidates form (cut chain)
     last_final = [None]                                             # rank 0: final hits of the last step (host array or pinned int64 pairs)
 
     # host landing zone for final hits (pinned: the copy out of HBM is part of every step)
@@ -404,16 +487,22 @@ def main():
         xb["mine"] = torch.zeros(1, dtype=torch.int64, device=cdev)
         xb["all"] = torch.zeros(world, dtype=torch.int64, device=cdev)
 
-    def exchange_counts(cnt, need):
-        """all_gather of the ranks' record counts; a rank whose scan overflowed sends -1.  Returns the
-        counts, or None when some rank has to scan again (then every rank does)."""
-        xb["mine"].fill_(-1 if need else cnt)
+    CUT = "cut"
+
+    def exchange_counts(cnt, need, cut=False):
+        """all_gather of the ranks' record counts; a rank whose scan overflowed sends -1, a rank whose owned finalize met
+        a chain of candidates cut by its guard band sends -2.  Returns the counts; None when some rank has to scan again
+        (then every rank does); CUT when some rank cannot decide its shard locally (then every rank takes the
+        gather-candidates form for this step, as GpuPatternMatch::sharded_scan does, host/gpu_pattern_match.cc)."""
+        xb["mine"].fill_(-1 if need else (-2 if cut else cnt))
         dist.all_gather_into_tensor(xb["all"], xb["mine"])
         cl = xb["all"].tolist()                                         # one host sync for all counts
-        if min(cl) < 0:
+        if -1 in cl:
             if need:
                 grow(need)
             return None
+        if -2 in cl:
+            return CUT
         return cl
 
     def timed_gather(ptr, cnt, cl, tx0):
@@ -465,13 +554,21 @@ def main():
     def step_owned():
         while True:
             ncand, need = scan(g_lo, g_hi)
-            ptr, cnt = (0, 0)
+            ptr, cnt, cut = 0, 0, False
             if not need:
                 # sort, clustering (and for -k the cluster DPs) on this rank's GPU; the final hits stay in HBM
-                ptr, cnt = pm.finalize_device(0, sort=False, owned=(begin, end, g_lo, None if ghi == total else g_hi), keep=True)
+                try:
+                    ptr, cnt = pm.finalize_device(0, sort=False, owned=(begin, end, g_lo, None if ghi == total else g_hi), keep=True)
+                except sat_amd.PmError as e:
+                    if e.code != -2:
+                        raise
+                    cut = True                                          # a same-pattern chain runs from the guard edge into the owned range
             # the path's one exchange: final hit records to rank 0 over xGMI
             tx0 = time.perf_counter()
-            cl = exchange_counts(cnt, need)
+            cl = exchange_counts(cnt, need, cut)
+            if cl is CUT:
+                cut_steps[0] += 1
+                return step_gather()
             if cl is not None:
                 break
         gathered = timed_gather(ptr, cnt, cl, tx0)
@@ -536,6 +633,29 @@ def main():
             last_final[0] = finalize_rank0(ptr, cnt, end)
             final_hits[0] = last_final[0].size
             return ncand
+        return step_gather()
+
+    merge = [None]
+
+    def merge_handle():
+        """rank 0, first use: a host-stage handle over the WHOLE stream (pm_init_host: pattern tables, no upload), for the
+        option sets whose verify reads stream text -- the counterpart of the merge handle of the command lines
+        (host/gpu_pattern_match.cc).  The synthetic stream is generated once more, block by block, into host memory."""
+        if merge[0] is None:
+            ent = args.entries * (world if args.scaling == "weak" else 1)
+            host = np.empty(total, dtype=np.uint8)
+            for b0 in range(0, total, BLOCK * 8):
+                b1 = min(total, b0 + BLOCK * 8)
+                host[b0:b1] = gen_stream(b0, b1, total, ent, 20260101, dev, args.stream_style, run).cpu().numpy()
+            m = sat_amd.PatternMatch(k=args.k, indels=bool(args.indels), kernel=kern, device=local)
+            for i, p in enumerate(allp):
+                m.add_pattern(p, i + 1)
+            m.init_host(host, TABLE)
+            merge[0] = m
+        return merge[0]
+
+    def step_gather():
+        """candidate records of every rank's own range -> rank 0, which clusters / verifies them in stream order"""
         while True:
             ncand, need = scan(begin, end)
             ptr, cnt = (0, 0) if need else pm.candidates_device()
@@ -556,7 +676,13 @@ def main():
             tot = allrec.shape[0]
             cand_count[0] = tot
             scanned = int(total)
-            last_final[0] = finalize_rank0(allrec.data_ptr(), tot, scanned)
+            if own_path and args.indels:
+                # filter_bitvec -k: the cluster DPs read the text around global positions, which no single GPU holds
+                m = merge_handle()
+                m.reset()
+                last_final[0] = m.finalize(allrec.cpu().numpy().view(sat_amd.HIT_DTYPE).reshape(-1), scanned, last=True, sort=False)
+            else:
+                last_final[0] = finalize_rank0(allrec.data_ptr(), tot, scanned)
             final_hits[0] = last_final[0].size
         return ncand
 
@@ -625,10 +751,12 @@ def main():
             key, kk = key[order], fin["k"][order]
             want = [(i, a, d) for (i, a, d) in planted if d <= args.k]
             found_planted = 0
+            if args.stream_style != "uniform" or args.plant_run:
+                tol = 1 << 38                                         # repeats: a chain of candidates has ONE hit, anywhere along the chain (filter_bitvec.cc:103-135)
             for (i, a, d) in want:
                 e = a + args.length
                 lo_i = np.searchsorted(key, ((i + 1) << 40) | max(0, e - tol))
-                hi_i = np.searchsorted(key, ((i + 1) << 40) | (e + tol), side="right")
+                hi_i = np.searchsorted(key, ((i + 1) << 40) | min(e + tol, (1 << 40) - 1), side="right")
                 if hi_i > lo_i and kk[lo_i:hi_i].min() <= d:
                     found_planted += 1
             planted = want
@@ -645,8 +773,16 @@ def main():
         evs = exch_events[args.warmup:]
         if evs:
             exch_dev_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    scan_stats = pm.scan_stats()
+    if scan_stats.get("blocks"):
+        # per block of 1024 positions and wave: rounds of the pair kernel's second pass, key hits per lane; key-hit rate per window test
+        scan_stats["rounds_per_block"] = scan_stats["rounds"] / scan_stats["blocks"]
+        scan_stats["key_hit_rate"] = scan_stats["key_hits"] / (scan_stats["blocks"] * 1024.0)
+    else:
+        for kx in ("blocks", "rounds", "key_hits"):
+            scan_stats.pop(kx, None)
     if rank == 0:
-        traffic, traffic_source = measured_traffic(args, shard)
+        traffic, traffic_source, traffic_entry = measured_traffic(args, shard)
         ms_per_step = dt / args.steps * 1e3
         value = n_bases_total / (dt / args.steps) / 1e9
         kms = float(np.mean(kernel_ms[args.warmup:])) if len(kernel_ms) > args.warmup else float("nan")
@@ -673,13 +809,19 @@ def main():
                        "semantics": pm.selected()[0], "kernel_family": pm.selected()[1], "kernel": desc,
                        "final_hits": final_hits[0], "candidates": cand_count[0],
                        "planted_found": None if found_planted is None else "%d of %d" % (found_planted, len(planted)),
-                       "rescans_after_overflow": rescans[0],
+                       "rescans_after_overflow": rescans[0], "steps_with_a_cut_chain": cut_steps[0],
+                       "stream_style": args.stream_style, "primer_source": args.primer_source,
+                       "scan_stats": scan_stats,
                        "stream": "1 B/base resident in HBM before the timed region; the handle's init (untimed, with the pattern tables) "
                                  "also derives its 2-bit form, which the seed kernels' first stage reads"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kms, "algorithmic_bytes": alg_bytes},
         }
+        if traffic_entry is not None:
+            st = staleness(traffic_entry, kms)
+            res["roofline"].update({"traffic_head": st["head"], "traffic_code_sha": st["code_sha_at_profile"], "code_sha_now": st["code_sha_now"],
+                                    "traffic_kernel_ms_at_profile": st["kernel_ms_at_profile"], "traffic_stale": st["stale"]})
         if use_dist:
             res["config"]["exchange"] = {"backend": backend, "forced_at_world_1": bool(force_dist),
                                          "form": "owned finalize on every rank, final hits gathered" if own_path else "candidate records gathered, rank 0 finalizes"}

@@ -234,6 +234,14 @@ int pm_describe(const pm_handle *h, char *buf, size_t buflen);
  * the handle's stream: milliseconds and number of launches. */
 int pm_last_kernel_time(pm_handle *h, float *ms, int *launches);
 
+/* Counters of the last scan, for measurement (bench.py --stream-style; no reference counterpart): out[0] candidate
+ * records; out[1] records handed from the first-stage kernel to the verify kernel (suspects of the pair plan, seed records
+ * of the edit / halves plans; the pattern tile with most); out[2] scans the library repeated on its own since pm_init
+ * because an internal buffer was too small (pm_last_kernel_time then covers every attempt); with PM_SEED_DEBUG bit 5 set
+ * on the pair plan also out[3] blocks of 1024 positions, out[4] rounds of its second pass, out[5] key hits, summed over
+ * waves and field pairs.  n <= 8 values are written. */
+int pm_scan_stats(pm_handle *h, uint64_t *out, int n);
+
 /* Duration of the one-off re-encoding of the stream to 2 bits per base that pm_init[_device] runs
  * for the seed kernel family (0 for the bit-parallel family): not part of a scan, reported so that a
  * reader can add it to a single cold pass. */

@@ -9,7 +9,26 @@ import os
 import shutil
 import sys
 
+import subprocess
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def head_of(code_sha):
+    """the commit the counters belong to: HEAD when the working tree's kernel sources hash to what the GPU box hashed
+    (bench.code_sha, recorded by scripts/pmc_*.sh), else unknown -- a counter file must never claim a commit it was not made on"""
+    try:
+        import bench
+        if code_sha and bench.code_sha() == code_sha:
+            h = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+            dirty = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "--", "sequence-alignment-tools_amd/csrc"]).returncode != 0
+            return h + ("+uncommitted" if dirty else "")
+    except Exception:
+        pass
+    return None
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
@@ -75,6 +94,7 @@ for k, fetch, write, kernel in ((2, "pmc_fetch_K2", "pmc_write_K2", "pm_pair_sca
 for f in sorted(glob.glob(os.path.join(G, "%s_traffic_*.json" % tag))):     # scripts/pmc_traffic.sh: one option set each
     with open(f) as fh:
         e = json.load(fh)
+    e["head"] = head_of(e.get("code_sha"))
     if e.get("FETCH_SIZE_KiB"):
         entries = [x for x in entries if (x["k"], x["indels"], x["db_bases"], x["primers"]) != (e["k"], e["indels"], e["db_bases"], e["primers"])] + [e]
 if entries:
@@ -87,6 +107,7 @@ issue = []
 for f in sorted(glob.glob(os.path.join(G, "%s_issue_*.json" % tag))):       # scripts/pmc_issue.sh: one option set each
     with open(f) as fh:
         e = json.load(fh)
+    e["head"] = head_of(e.get("code_sha"))
     if e.get("SQ_INSTS_VALU") or e.get("TCP_TCC_READ_REQ_sum"):
         issue.append(e)
 if issue:

@@ -1,11 +1,16 @@
-"""Long differential fuzz on the GPU box: the seed family (pair plan, edit plan, halves) against the
-bit-parallel family on streams made to be hard for the seed kernels -- low-complexity text built from a
-small vocabulary of words, tandem repeats, primers cut from the stream and mutated -- so that most
-windows are key hits, lanes run out of pending-hit bits, suspect queues flush all the time and the
-record buffers overflow.  The two families share no code before the final stage; small slices are
-also checked against the oracle.
+"""Long differential fuzz on the GPU box, two forms.
 
-    python scripts/fuzz_families.py [seconds] [first_seed]
+Default: the seed family (pair plan, edit plan, halves) against the bit-parallel family on streams made to be hard for
+the seed kernels (tests/adversarial.py: low-complexity text built from a small vocabulary of words, tandem repeats,
+primers cut from the stream and mutated), streams of 64 Ki .. 2 Mi characters and one case in twelve of 20 .. 400 Mbp.
+The two families share no code before the final stage -- and everything from there on, so a bug in pm_finalize, the
+host cluster / halves rules or the stream-edge records is invisible to this form.
+
+--oracle: the library (its own choice of kernel family) against oracle/pm_oracle.c, the CPU restatement pinned to the real
+reference, on the small cases of tests/adversarial.py (300 .. 8000 characters: what the oracle finishes in well under a
+second) -- the open-ended form of tests/test_gpu_adversarial.py, which keeps 72 fixed seeds in the suite.
+
+    python scripts/fuzz_families.py [seconds] [first_seed] [--oracle]
 
 Prints one line per case and a summary; exit status 1 on the first difference."""
 import os
@@ -19,61 +24,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import sat_amd  # noqa: E402
+import adversarial as A  # noqa: E402
+from adversarial import make_stream, make_patterns  # noqa: E402
 
 TABLE = b"ACGT\n"
 LUT = np.frombuffer(b"ACGT", dtype=np.uint8)
-
-
-def make_stream(rng, n, style):
-    """codes 0..3, code 4 = end of an entry"""
-    if style == 0:                                                 # uniform
-        s = rng.integers(0, 4, n, dtype=np.uint8)
-    elif style == 1:                                               # skewed composition
-        s = rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35]).astype(np.uint8)
-    elif style == 2:                                               # words of a small vocabulary, 2 % point mutations
-        wl = int(rng.integers(5, 13))
-        vocab = rng.integers(0, 4, (int(rng.integers(4, 200)), wl), dtype=np.uint8)
-        s = vocab[rng.integers(0, vocab.shape[0], n // wl + 1)].reshape(-1)[:n].copy()
-        m = rng.random(n) < 0.02
-        s[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
-    else:                                                          # tandem repeats of short units with drifting copies
-        s = np.empty(n, dtype=np.uint8)
-        at = 0
-        while at < n:
-            unit = rng.integers(0, 4, int(rng.integers(1, 40)), dtype=np.uint8)
-            reps = int(rng.integers(1, 400))
-            blk = np.tile(unit, reps)
-            m = rng.random(blk.size) < 0.03
-            blk[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
-            blk = blk[: n - at]
-            s[at:at + blk.size] = blk
-            at += blk.size
-    for _ in range(int(rng.integers(0, 4))):                       # entry ends
-        s[int(rng.integers(0, n))] = 4
-    return s
-
-
-def make_patterns(rng, s, count, lo, hi, k):
-    out = []
-    n = s.size
-    while len(out) < count:
-        L = int(rng.integers(lo, hi + 1))
-        a = int(rng.integers(0, n - L))
-        w = s[a:a + L]
-        if (w > 3).any():
-            continue
-        p = LUT[w].tobytes().decode()
-        for _ in range(int(rng.integers(0, k + 2))):               # 0 .. k+1 edits
-            kind = int(rng.integers(0, 4))
-            i = int(rng.integers(0, len(p)))
-            if kind <= 1:
-                p = p[:i] + "ACGT"[int(rng.integers(0, 4))] + p[i + 1:]
-            elif kind == 2 and len(p) < hi:
-                p = p[:i] + "ACGT"[int(rng.integers(0, 4))] + p[i:]
-            elif kind == 3 and len(p) > lo:
-                p = p[:i] + p[i + 1:]
-        out.append(p)
-    return out
 
 
 def sort3(end, pid, k):
@@ -123,9 +78,47 @@ def hits_of(pats, k, indels, kernel, sem, dev, cap, mode=0, rng=None, table=TABL
     return sort3(h["end"], h["pid"], h["k"]) + (sel, desc)
 
 
+def main_oracle(budget, seed):
+    """small adversarial cases, library against oracle"""
+    t_end = time.time() + budget
+    cases = bad = skipped = 0
+    fam = {sat_amd.KERNEL_SEED: 0, sat_amd.KERNEL_BITPAR: 0}
+    while time.time() < t_end:
+        c = A.small_case(seed)
+        want = A.oracle_hits(c)
+        note = ""
+        try:
+            got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO)
+        except sat_amd.PmError as err:
+            if want is None and err.code in (-6, -2):
+                skipped += 1
+                seed += 1
+                continue
+            if err.code != -2 or c["mode"] < 2:
+                raise
+            note = " (mode %d not available: %s; resumable scan instead)" % (c["mode"], str(err)[:60])
+            got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO, mode=1)
+        cases += 1
+        fam[c["selected"][1]] += 1
+        same = want is not None and got == want
+        print("%s: %d hits %s%s  %s" % (A.describe(c), len(got), "ok" if same else "DIFFERENT (oracle %s)" % (None if want is None else len(want)), note, c["kernel_desc"][:50]), flush=True)
+        if not same:
+            bad += 1
+            sg, sw = set(got), set(want or [])
+            print("  only GPU:", sorted(sg - sw)[:8], " only oracle:", sorted(sw - sg)[:8], flush=True)
+            break
+        seed += 1
+    print("oracle form: cases %d (seed family %d, bit-parallel family %d), rejected by reference and library alike %d, failures %d, next seed %d" % (
+        cases, fam[sat_amd.KERNEL_SEED], fam[sat_amd.KERNEL_BITPAR], skipped, bad, seed))
+    sys.exit(1 if bad else 0)
+
+
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    argv = [a for a in sys.argv[1:] if a != "--oracle"]
+    budget = float(argv[0]) if len(argv) > 0 else 300.0
+    seed = int(argv[1]) if len(argv) > 1 else 1000
+    if "--oracle" in sys.argv[1:]:
+        return main_oracle(budget, seed)
     t_end = time.time() + budget
     cases = bad = 0
     sems = [(sat_amd.SEM_AUTO, "auto"), (sat_amd.SEM_SHIFT_AND_INEXACT, "sai"), (sat_amd.SEM_FILTER_BITVEC, "fbv"), (sat_amd.SEM_EXACT_HALVES, "halves"),

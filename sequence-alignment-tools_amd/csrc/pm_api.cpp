@@ -64,6 +64,7 @@ struct pm_handle {
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool bases_flags = false;           // exact_bases -K on whole-pattern Hamming candidates with clean exact zones (pair plan): records are final
   bool zoned = false;                 // some pattern has exact-base constraints
+  bool nn_quirk = false;              // -w without -W on a stream that holds N, and some pattern has the letter N (pattern_n_quirk)
   bool wild_seed = false;             // -w/-W on the seed family: primers with <= 2 ambiguity letters expanded into their concrete variants
   bool bases_edits = false;           // exact_bases -k on the seed family: the k-error automaton's candidates -> block seeds (pm_bases_seeds)
   int64_t own_begin = 0, own_end = 0; //   the range the caller asked for (the candidates are scanned a little wider)
@@ -105,6 +106,7 @@ struct pm_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   int last_launches = 0;
+  unsigned long long internal_rescans = 0;   // scans repeated inside pm_scan_wait since pm_init (an internal buffer was too small)
   ScanGeometry geo{};
 
   // host stage state
@@ -154,6 +156,9 @@ struct pm_handle {
 
   std::string err;
 };
+
+// per-tile record counts between a scan's first-stage and verify kernels: [0] unused, [1 + t] tile t, then 8 measurement counters
+constexpr size_t SEEDCOUNT_WORDS = 1 + 256 + 8;
 
 static thread_local std::string g_create_error;
 
@@ -373,6 +378,18 @@ static bool stream_letters_plain(const pm_handle *h) {
   }
   return true;
 }
+// The one letter pair on which the reference's automaton and its verify DP disagree: pattern N at a stream N under -w
+// without -W.  The mask build leaves the stream's N out of every class (shift_and.cc:112: `wccompat[j]!='N' || _textn`),
+// so the automaton counts a substitution there; the DP looks for EQUAL characters first (pattern_alignment.cc:314-316)
+// and charges nothing.  filter_bitvec's hit value is the DP's, so for such a pattern it cannot be read off the
+// candidate levels (found by tests/test_gpu_adversarial.py against the oracle; both kernel families shared the shortcut).
+static bool stream_has_N(const pm_handle *h) {
+  const int c = h->alpha.nch[(unsigned char)'N'];
+  return c >= 0 && c < 256 && h->alpha.present[c];
+}
+static bool pattern_n_quirk(const pm_handle *h, const Pattern &p) {
+  return h->cfg.wildcards && !h->cfg.text_n && p.s.find('N') != std::string::npos && stream_has_N(h);
+}
 // concrete variants of a primer (at most `cap`; empty + false when there would be more)
 static bool expand_iupac(const std::string &p, size_t cap, std::vector<std::string> *out) {
   out->assign(1, std::string());
@@ -468,6 +485,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->seed_flags = false; h->bases_flags = false; h->bases_edits = false; h->half_ranked_any = false;
   h->zoned = false;
   for (const Pattern &p : h->pats) h->zoned = h->zoned || p.esb || p.eeb;
+  h->nn_quirk = false;
+  for (const Pattern &p : h->pats) h->nn_quirk = h->nn_quirk || pattern_n_quirk(h, p);
   h->start_cached = false; h->start_cache.clear(); h->end_cached = false; h->end_cache.clear(); h->overhang_cached = false; h->overhang_cache.clear(); h->edge_cached = false; h->edge_cache.clear(); h->head_cached = false; h->head_cache.clear();
   std::string why;
   bool want_seed = h->kern == PM_KERNEL_SEED || h->kern == PM_KERNEL_AUTO;
@@ -486,7 +505,8 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     for (size_t i = 0; i < h->inner.size(); ++i) {
       const std::string &ps = h->inner[i].s;
       bool ok = ps.size() <= 32 && ps.size() >= (edits_plan ? 20u : 10u);
-      if (h->wild_seed) ok = ok && expand_iupac(ps, 16, &variants);   // up to two ambiguity letters (16 variants)
+      if (h->wild_seed) ok = ok && expand_iupac(ps, 16, &variants) &&   // up to two ambiguity letters (16 variants)
+                         !(h->sem == PM_SEM_FILTER_BITVEC && pattern_n_quirk(h, h->inner[i]));   // (its value needs the text-based verify)
       else for (unsigned char ch : ps) ok = ok && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
       if (!ok) { h->in_rest[i] = 1; ++h->nrest; }
     }
@@ -664,7 +684,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   }
   if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, sizeof(unsigned long long)));
   if (!h->h_counter) HIP_TRY(h, hipHostMalloc((void **)&h->h_counter, sizeof(unsigned long long), hipHostMallocDefault));
-  if (!h->h_seed_count) { HIP_TRY(h, hipHostMalloc((void **)&h->h_seed_count, (1 + 256) * sizeof(unsigned long long), hipHostMallocDefault)); memset(h->h_seed_count, 0, (1 + 256) * sizeof(unsigned long long)); }
+  if (!h->h_seed_count) { HIP_TRY(h, hipHostMalloc((void **)&h->h_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long), hipHostMallocDefault)); memset(h->h_seed_count, 0, SEEDCOUNT_WORDS * sizeof(unsigned long long)); }
   if (!h->ev0) HIP_TRY(h, hipEventCreate(&h->ev0));
   if (!h->ev1) HIP_TRY(h, hipEventCreate(&h->ev1));
   if (!h->host_only) {
@@ -677,6 +697,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     if (h->cap < want) { rc = ensure_capacity(h, want); if (rc) return rc; }
   }
   device_sort_plan(h);
+  h->internal_rescans = 0;
   h->inited = true;
   return pm_reset(h);
 }
@@ -888,10 +909,10 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
       h->seed_cap = std::max(h->seed_cap, want_seeds);
       HIP_TRY(h, hipMalloc((void **)&h->d_seeds, h->seed_cap * sizeof(uint64_t)));
     }
-    if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, (1 + 256) * sizeof(unsigned long long)));
+    if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long)));
     const int ntiles = 1 + (int)h->sd_more.size();
     if (ntiles > 256) return fail(h, PM_E_UNSUPPORTED, "too many pattern tiles for the edit-distance plan");
-    HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, (1 + 256) * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, SEEDCOUNT_WORDS * sizeof(unsigned long long), h->stream));
     for (int t = 0; t < ntiles; ++t) {
       EditStage es; es.d_seeds = h->d_seeds; es.d_seed_count = h->d_seed_count + 1 + t; es.seed_cap = h->seed_cap; es.tile = t;
       if (h->bases_edits) {
@@ -901,7 +922,7 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
       const SeedDevice &d = t == 0 ? h->sd : h->sd_more[t - 1];
       HIP_TRY(h, seed_launch(d, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 ? &h->geo : nullptr, &es));
     }
-    HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->last_launches = 2 * ntiles;
     if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }
@@ -916,13 +937,13 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
       h->susp_cap = std::max(h->susp_cap, want);
       HIP_TRY(h, hipMalloc(&h->d_susp, h->susp_cap * PAIR_SUSPECT_BYTES));
     }
-    if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, (1 + 256) * sizeof(unsigned long long)));
+    if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long)));
     if (h->pair.size() > 256) return fail(h, PM_E_UNSUPPORTED, "too many pattern tiles");
-    HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, (1 + 256) * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, SEEDCOUNT_WORDS * sizeof(unsigned long long), h->stream));
     for (size_t t = 0; t < h->pair.size(); ++t)
       HIP_TRY(h, pair_launch(h->pair[t], h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap,
-                             h->d_susp, h->d_seed_count + 1 + t, h->susp_cap, h->stream, t == 0 ? &h->geo : nullptr));
-    HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, (1 + 256) * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+                             h->d_susp, h->d_seed_count + 1 + t, h->susp_cap, h->stream, t == 0 ? &h->geo : nullptr, h->d_seed_count + 257));
+    HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->last_launches = 2 * (int)h->pair.size();
     if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }
@@ -1361,9 +1382,12 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
 
 extern "C" int pm_scan_wait(pm_handle *h, size_t *n_out) {
   if (!h || !h->scan_pending) return fail(h, PM_E_INVALID, "pm_scan_wait: no scan in flight");
+  float spent_ms = 0.f;                                             // kernel time of the attempts that had to be repeated
   for (int tries = 0;; ++tries) {
     const int rc = scan_wait_once(h, n_out);
-    if (rc != SCAN_AGAIN) return rc;
+    if (rc != SCAN_AGAIN) { h->last_ms += spent_ms; return rc; }
+    spent_ms += h->last_ms;
+    ++h->internal_rescans;
     if (tries >= 8) return fail(h, PM_E_NOMEM, "pm_scan_wait: the scan's internal record buffers keep overflowing");
     const int ra = pm_scan_candidates_async(h, h->own_begin, h->own_end);   // the caller's range, with the enlarged buffer
     if (ra) return ra;
@@ -1397,6 +1421,20 @@ extern "C" int pm_candidates_device(pm_handle *h, void **d_records, size_t *n) {
   if (!h || !h->inited) return PM_E_INVALID;
   if (d_records) *d_records = h->d_cands;
   if (n) *n = h->last_count;
+  return PM_OK;
+}
+
+extern "C" int pm_scan_stats(pm_handle *h, uint64_t *out, int n) {
+  if (!h || !h->inited || !out || n < 0) return PM_E_INVALID;
+  uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  v[0] = h->last_count;
+  if (h->h_seed_count) {
+    const size_t tiles = !h->pair.empty() ? h->pair.size() : 1 + h->sd_more.size();
+    for (size_t t = 0; t < tiles && t < 256; ++t) v[1] = std::max<uint64_t>(v[1], h->h_seed_count[1 + t]);
+    v[3] = h->h_seed_count[257]; v[4] = h->h_seed_count[258]; v[5] = h->h_seed_count[259];
+  }
+  v[2] = h->internal_rescans;
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return PM_OK;
 }
 
@@ -1570,7 +1608,7 @@ int finalize_filter_bitvec(pm_handle *h, const pm_hit *cands, size_t n, int64_t 
       const int64_t c_first = g[i].end, c_last = g[j - 1].end;
       if (!last && scanned_to < c_last + win) {                     // :118-121: the cluster may still grow
         keep.insert(keep.end(), g.begin() + i, g.begin() + j);
-      } else if (!indels && p.esb == 0 && p.eeb == 0 && c_first >= L) {
+      } else if (!indels && p.esb == 0 && p.eeb == 0 && c_first >= L && !(h->nn_quirk && pattern_n_quirk(h, p))) {
         // Substitution-only search without exact-base constraints needs no text: the DP
         // (pattern_alignment.cc with b = 0) walks diagonals only, so the cluster's value is the
         // smallest Hamming distance among its windows -- the smallest candidate level, windows that
@@ -1829,6 +1867,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
 // (pm_cluster.hip), no stream text needed
 static bool device_cluster_plain(const pm_handle *h) {
   if (!(h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.indels && h->cfg.k <= 3 && h->pats.size() < ((size_t)1 << 22))) return false;
+  if (h->nn_quirk) return false;                                    // pattern N at a stream N under -w: the value is the DP's (pattern_n_quirk)
   // with exact-base constraints only on the pair plan, whose records mark zone violations (level 3, k <= 2)
   if (h->zoned) return h->kern == PM_KERNEL_SEED && !h->pair.empty() && h->nrest == 0 && h->cfg.k <= 2;
   return true;

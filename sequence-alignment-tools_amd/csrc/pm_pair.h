@@ -70,6 +70,6 @@ ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end);
 constexpr size_t PAIR_SUSPECT_BYTES = 16;
 hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, void *d_susp, unsigned long long *d_susp_count, uint64_t susp_cap,
-                       hipStream_t st, ScanGeometry *geo_out);
+                       hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats = nullptr);
 
 }  // namespace pm

@@ -98,6 +98,7 @@ struct PairArgs {
   uint4 *susp;                          // suspect records for pm_pair_verify: {key, other fields, position | combo << 40}
   unsigned long long *susp_count;
   unsigned long long susp_cap;
+  unsigned long long *stats;            // measurement (debug & 32): [0] blocks of 1024 positions, [1] rounds, [2] key hits, over waves and field pairs
 };
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -493,6 +494,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     });
   };
 
+  const bool stats = (a.debug & 32) != 0 && a.stats != nullptr;     // wave-uniform measurement switch (bench.py --stream-style)
+  uint32_t st_blocks = 0, st_rounds = 0, st_hits = 0;
   int64_t bb = ws;
   const int rmin = (a.debug >> 8) & 15 ? (a.debug >> 8) & 15 : 2;   // rounds per block at least (measurement knob in the debug word)
   while (bb < own_hi) {
@@ -527,6 +530,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       });
     }
     P |= acc & (own << 16);
+    if (stats) { st_hits += (uint32_t)__popc(acc & (own << 16)); ++st_blocks; }
     cu1 = __builtin_amdgcn_alignbit(prev1, prev2, 26); cu2 = __builtin_amdgcn_alignbit(cur, prev1, 26); cu3 = cur >> 26;
     // pass B (skipped while no lane has a hit pending and the pipeline has run empty: sparse pattern sets)
     if (__ballot(P != 0)) quiet = 0;
@@ -534,6 +538,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       int r = 0;
       do { two_rounds(); r += 2; } while (r < rmin || __ballot((P & 0xffffu) != 0));
       quiet += r;
+      st_rounds += (uint32_t)r;
     }
     P >>= 16; pu1 = cu1; pu2 = cu2; pu3 = cu3; tagbase += 16u;
     bb += 1024;
@@ -542,6 +547,10 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   for (int d = 0; d < NR / 2 + 1; ++d) two_rounds();                // and what is still in the pipeline
   if (keep == 0x9e3779b9u) a.susp[0] = make_uint4(keep, 0, 0, 0);   // (measurement switch: the verdicts must stay alive)
   flush();
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) st_hits += (uint32_t)__shfl_xor((int)st_hits, o);
+    if (lane == 0) { atomicAdd(a.stats, (unsigned long long)st_blocks); atomicAdd(a.stats + 1, (unsigned long long)st_rounds); atomicAdd(a.stats + 2, (unsigned long long)st_hits); }
+  }
 }
 
 __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_scan(PairArgs a) {
@@ -752,7 +761,7 @@ ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end) {
 
 hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, void *d_susp, unsigned long long *d_susp_count, uint64_t susp_cap,
-                       hipStream_t st, ScanGeometry *geo_out) {
+                       hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats) {
   if (!d_packed) return hipErrorInvalidValue;
   if (end > n) end = n;
   ScanGeometry g = pair_geometry(d, begin, end);
@@ -775,6 +784,7 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   a.out = d_out; a.counter = d_counter; a.cap = cap;
   if (!d_susp || !d_susp_count) return hipErrorInvalidValue;
   a.susp = reinterpret_cast<uint4 *>(d_susp); a.susp_count = d_susp_count; a.susp_cap = susp_cap;   // *d_susp_count zeroed by the caller (stream order)
+  a.stats = d_stats;
   hipLaunchKernelGGL(pm_pair_scan, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
   hipError_t ce = hipGetLastError();
   if (ce != hipSuccess) return ce;

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
-    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host",
+    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host", "pm_scan_stats",
     "pm_comm_unique_id", "pm_comm_create", "pm_comm_gather", "pm_comm_destroy", "pm_comm_last_error",
 ]
 
@@ -76,6 +76,7 @@ def load_library():
         L.pm_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
         L.pm_add_pattern.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_int32, C.c_int32]
         L.pm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        L.pm_init_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
         L.pm_init_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.pm_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.pm_scan_view.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -99,6 +100,7 @@ def load_library():
         L.pm_measure_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         L.pm_final_hits_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.pm_copy_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pm_scan_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.pm_pack_time.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
@@ -184,6 +186,15 @@ class PatternMatch:
         self._keep = arr                      # pm_init borrows the host pointer
         tb = None if table is None else (C.c_uint8 * len(table)).from_buffer_copy(bytes(table))
         self._check(self._L.pm_init(self._h, arr.ctypes.data_as(C.c_void_p), arr.size, tb, 0 if table is None else len(table)))
+        self._n, self._pos = arr.size, 0
+
+    def init_host(self, text, table=None):
+        """pm_init_host: a handle that runs the HOST stage only (finalize, align_hits) over the whole stream -- the merge
+        rank of a position-sharded scan."""
+        arr = np.ascontiguousarray(text, dtype=np.uint8)
+        self._keep = arr
+        tb = None if table is None else (C.c_uint8 * len(table)).from_buffer_copy(bytes(table))
+        self._check(self._L.pm_init_host(self._h, arr.ctypes.data_as(C.c_void_p), arr.size, tb, 0 if table is None else len(table)))
         self._n, self._pos = arr.size, 0
 
     def init_device(self, data_ptr, n, table=None, stream=None, keepalive=None):
@@ -350,6 +361,13 @@ class PatternMatch:
         buf = C.create_string_buffer(512)
         self._check(self._L.pm_describe(self._h, buf, 512))
         return buf.value.decode()
+
+    def scan_stats(self):
+        """pm_scan_stats: counters of the last scan (see include/pm_gpu.h)"""
+        v = (C.c_uint64 * 8)()
+        self._check(self._L.pm_scan_stats(self._h, v, 8))
+        names = ("candidates", "between_stages", "internal_rescans", "blocks", "rounds", "key_hits")
+        return {k: int(v[i]) for i, k in enumerate(names)}
 
     def pack_time(self):
         ms = C.c_float()
