@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--stream-style", choices=list(STYLES), default="uniform", help="composition of the synthetic stream (gen_block)")
     ap.add_argument("--primer-source", choices=["auto", "mixed", "stream"], default="auto",
                     help="mixed: 10 %% of the primers cut from the stream (SURVEY 8d); stream: all of them; auto: mixed on the uniform stream, stream on the others")
+    ap.add_argument("--landing", type=int, default=1 << 24, help="records the host landing zones hold (hit-dense streams need more)")
     ap.add_argument("--pair-stats", action="store_true", help="count blocks, rounds and key hits in the pair kernel (PM_SEED_DEBUG bit 5; a measurement build of the same kernel)")
     ap.add_argument("--plant-run", type=int, default=0, help="A x this many across the middle of the stream, and the primer A x length with it")
     ap.add_argument("--scan-passes", type=int, default=3, help="timed whole-stream passes through pm_scan itself after the timed region (0 = skip; single GPU only)")
@@ -449,16 +450,16 @@ def main():
     last_final = [None]                                             # rank 0: final hits of the last step (host array or pinned int64 pairs)
 
     # host landing zone for final hits (pinned: the copy out of HBM is part of every step)
-    out_pin = torch.empty((1 << 24) * 16, dtype=torch.uint8, pin_memory=True)
+    out_pin = torch.empty(args.landing * 16, dtype=torch.uint8, pin_memory=True)
     out_buf = out_pin.numpy().view(sat_amd.HIT_DTYPE)
     # filter_bitvec: every rank clusters and verifies what it owns; only final hits travel
     own_path = use_dist and pm.selected()[0] == sat_amd.SEM_FILTER_BITVEC
     g_lo = 0 if glo == 0 else begin - GUARD
     g_hi = stream.numel() if ghi == total else end + GUARD
     land_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
-    one_pin = torch.empty((1 << 24) * 2, dtype=torch.int64, pin_memory=True) if rank == 0 and not use_dist else None
+    one_pin = torch.empty(args.landing * 2, dtype=torch.int64, pin_memory=True) if rank == 0 and not use_dist else None
     landed = [None, False]                                          # single rank: event of the copy in flight; does it read the candidate buffer itself?
-    all_pin = torch.empty((1 << 24) * 2 * (world if own_path else 1), dtype=torch.int64, pin_memory=True) if rank == 0 and own_path else None
+    all_pin = torch.empty(args.landing * 2 * (world if own_path else 1), dtype=torch.int64, pin_memory=True) if rank == 0 and own_path else None
     dev_final = [True]                                              # GPU clustering available for this option set?
 
     def scan(lo_, hi_):
@@ -707,7 +708,7 @@ def main():
     pm_scan_ms, pm_scan_hits, scan_hits_arr = None, None, None
     if not use_dist and args.scan_passes > 0:
         torch.cuda.synchronize()
-        caller = np.zeros(1 << 24, dtype=sat_amd.HIT_DTYPE)
+        caller = np.zeros(args.landing, dtype=sat_amd.HIT_DTYPE)
         times = []
         for _ in range(args.scan_passes + 1):                       # first pass untimed (buffers grow to their working size)
             pm.reset()

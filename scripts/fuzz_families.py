@@ -8,7 +8,7 @@ host cluster / halves rules or the stream-edge records is invisible to this form
 
 --oracle: the library (its own choice of kernel family) against oracle/pm_oracle.c, the CPU restatement pinned to the real
 reference, on the small cases of tests/adversarial.py (300 .. 8000 characters: what the oracle finishes in well under a
-second) -- the open-ended form of tests/test_gpu_adversarial.py, which keeps 72 fixed seeds in the suite.
+second) -- the open-ended form of tests/test_gpu_adversarial.py, which keeps 600 fixed seeds in the suite.
 
     python scripts/fuzz_families.py [seconds] [first_seed] [--oracle]
 

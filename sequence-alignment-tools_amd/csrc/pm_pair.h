@@ -34,6 +34,7 @@ struct PairTables {                                 // one pattern tile
   std::vector<uint32_t> row_base;                   // [combo][PAIR_BITMAP_WORDS + 1]: keys that occur in front of every row (rank of a key = row_base[row] + rank in row)
   std::vector<uint32_t> first_pat;                  // [combo][distinct keys + 1]: by rank, first index into order[] of every key
   std::vector<uint32_t> order;                      // [combo][np]: pattern indices sorted by key
+  std::vector<uint32_t> olist;                      // [combo][np]: the other 20 window bits of order[]'s patterns (pm_pair_verify walks a key's run here)
   size_t first_off[PAIR_MAX_COMBOS] = {};           // per combo, in elements of first_pat
   std::vector<uint64_t> pat40;                      // last 20 bases, 2 bits each
   std::vector<uint8_t> pat_len;
@@ -49,7 +50,7 @@ struct PairDevice {
   size_t first_off[PAIR_MAX_COMBOS] = {};
   size_t np = 0;
   uint64_t *slots = nullptr;
-  uint32_t *image = nullptr, *row_base = nullptr, *first_pat = nullptr, *order = nullptr, *pat_id = nullptr;
+  uint32_t *image = nullptr, *row_base = nullptr, *first_pat = nullptr, *order = nullptr, *olist = nullptr, *pat_id = nullptr;
   uint64_t *pat40 = nullptr;
   uint8_t *pat_len = nullptr, *pat_codes = nullptr;
   uint32_t *pat_zone = nullptr;

@@ -83,6 +83,7 @@ struct PairArgs {
   const uint2 *slots;                   // [combo][PAIR_BITMAP_WORDS * stride]
   const uint32_t *row_base;             // [combo][PAIR_BITMAP_WORDS + 1]: distinct keys in front of every row
   const uint32_t *first_pat, *order;    // [combo][distinct keys + 1] (by rank), [combo][np]: patterns sorted by key
+  const uint32_t *olist;                // [combo][np]: the OTHER 20 window bits of order[]'s patterns, in the same sequence (a key's run is contiguous)
   uint32_t first_off[PAIR_MAX_COMBOS];
   uint32_t np;
   const uint2 *pat40;
@@ -210,20 +211,34 @@ __device__ __forceinline__ bool pair_verify(const PairArgs &a, int combo, int64_
   return true;
 }
 
-// Append the records of the lanes that have one (`ok`; called by whichever lanes of the wave are
-// executing together): one atomic per wave and call -- the first lane with a record reserves the slots
-// of all of them -- instead of one per record on the single shared counter (same-address atomics
-// serialise at ~2.5 ns each; 10^6 records per launch).
-__device__ __forceinline__ void pair_emit(const PairArgs &a, bool ok, const pm_hit &hh) {
+// Output of the verify kernel.  The record list's end is ONE counter for the whole grid and same-address atomics
+// serialise (~10 ns each under load), so a workgroup collects its records in LDS and appends them in batches: one atomic
+// per ~1500 records instead of one per wave and call (hit-dense streams -- tandem repeats, 0.4 candidates per base --
+// spent most of this kernel waiting for that counter).  Called by whichever lanes of a wave are executing together.
+constexpr int VSTAGE = 2048;                                        // records a workgroup stages (32 KiB)
+struct VerifyStage { pm_hit *rec; uint32_t *fill, *valid; };        // LDS: records, reserved slots, first slot that was refused
+
+__device__ __forceinline__ void pair_emit(const PairArgs &a, const VerifyStage &vs, bool ok, const pm_hit &hh) {
   const unsigned long long bal = __ballot(ok);
   if (bal == 0) return;
   const int leader = __ffsll((long long)bal) - 1;
   const int lane = threadIdx.x & 63;
+  const uint32_t cnt = (uint32_t)__popcll(bal), mine = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+  uint32_t pos = 0;
+  if (lane == leader) pos = atomicAdd(vs.fill, cnt);
+  pos = __builtin_amdgcn_readlane(pos, leader);
+  if (pos + cnt <= (uint32_t)VSTAGE) {
+    if (ok) vs.rec[pos + mine] = hh;
+    return;
+  }
+  // no room (a workgroup whose suspects give thousands of records in one trip): this batch goes straight to the list;
+  // every later reservation of the trip is refused as well (fill stays above VSTAGE), the flush takes the slots in front
+  if (lane == leader) atomicMin(vs.valid, pos);
   unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)__popcll(bal));
+  if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)cnt);
   const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
   if (ok) {
-    const unsigned long long o = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+    const unsigned long long o = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)mine;
     if (o < a.cap) a.out[o] = hh;
   }
 }
@@ -231,9 +246,10 @@ __device__ __forceinline__ void pair_emit(const PairArgs &a, bool ok, const pm_h
 // A suspect: a window whose slot says "within k on the other fields" for the key's first / second /
 // third pattern (what & 1, 2, 4), that the key has more than three (WHAT_REST: walk the rest of the
 // key's run of the sorted pattern list), or whose key has no slot (WHAT_ALL: walk the whole run).
-__device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint32_t rank, uint32_t what, uint32_t wo, int64_t p, pm_hit *first, bool *have) {
+__device__ __forceinline__ void pair_resolve(const PairArgs &a, const VerifyStage &vs, int combo, uint32_t rank, uint32_t what, uint32_t wo, int64_t p, pm_hit *first, bool *have) {
   const uint32_t *fp = a.first_pat + a.first_off[combo];
   const uint32_t *ord = a.order + (size_t)combo * a.np;
+  const uint32_t *ol = a.olist + (size_t)combo * a.np;
   const uint32_t t0 = fp[rank], t1 = fp[rank + 1];
   pm_hit hh;
   // the suspect's first record stays in registers (the kernel writes those block by block), further ones -- a
@@ -241,20 +257,16 @@ __device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint3
   auto take = [&](bool ok) __attribute__((always_inline)) {
     const bool extra = ok && *have;
     if (ok && !*have) { *first = hh; *have = true; }
-    pair_emit(a, extra, hh);
+    pair_emit(a, vs, extra, hh);
   };
   for (uint32_t j = 0; j < 3; ++j)
     take(((what >> j) & 1u) && t0 + j < t1 && pair_verify(a, combo, p, ord[t0 + j], &hh));   // (free slot fields repeat the first pattern)
   if (what & (WHAT_REST | WHAT_ALL)) {
-    int c, d;
-    other_fields(a.fa[combo], a.fb[combo], &c, &d);
-    for (uint32_t t = t0 + ((what & WHAT_ALL) ? 0u : 3u); t < t1; ++t) {
-      const uint32_t pi = ord[t];
-      const uint2 pp = a.pat40[pi];
-      const uint64_t W = ((uint64_t)pp.y << 32) | pp.x;
-      const uint32_t po = field_of(W, c) | (field_of(W, d) << 10);
-      take(sym_distance(po ^ wo) <= a.k && pair_verify(a, combo, p, pi, &hh));
-    }
+    // the rest of the key's run: its patterns' other fields lie next to each other (one or two cache lines for a run of
+    // twenty; ord[] -> pat40[] was two dependent random loads per pattern -- keys shared by many primers are what a
+    // skewed stream with primers cut from it is made of)
+    for (uint32_t t = t0 + ((what & WHAT_ALL) ? 0u : 3u); t < t1; ++t)
+      take(sym_distance(ol[t] ^ wo) <= a.k && pair_verify(a, combo, p, ord[t], &hh));
   }
 }
 
@@ -265,12 +277,24 @@ __device__ __forceinline__ void pair_resolve(const PairArgs &a, int combo, uint3
 // 256 suspects -- one per wave and emit call, 10^5 to 10^6 per launch on one address at ~2 ns each, was 1.7 of
 // this kernel's 2.0 ms.
 __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
+  __shared__ pm_hit s_rec[VSTAGE];
   __shared__ unsigned long long s_base;
-  __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_fill, s_valid, s_full;
+  const VerifyStage vs = {s_rec, &s_fill, &s_valid};
   unsigned long long n = *a.susp_count;
   if (n > a.susp_cap) n = a.susp_cap;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { s_fill = 0; s_valid = (uint32_t)VSTAGE; }
+  __syncthreads();
+  // the staged records join the list: one atomic for all of them (block-uniform call)
+  auto flush = [&]() __attribute__((always_inline)) {
+    const uint32_t cnt = min(s_fill, s_valid);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_base = cnt ? atomicAdd(a.counter, (unsigned long long)cnt) : 0ull; s_fill = 0; s_valid = (uint32_t)VSTAGE; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) if (s_base + i < a.cap) a.out[s_base + i] = s_rec[i];
+    __syncthreads();
+  };
   for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n; base += stride) {   // block-uniform trip count
     const unsigned long long i = base + threadIdx.x;
     pm_hit first;
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
     if (i < n) {
       const uint4 r = a.susp[i];
       const uint64_t pw = ((uint64_t)r.w << 32) | r.z;
+      if (r.x != 0xffffffffu) {                                       // (a slot its wave reserved and did not need)
       const int combo = (int)((pw >> 40) & 7u);
       // the key's row of the bitmap (global copy) -> rank; its slot -> which of its patterns are within k on the other fields
       const uint32_t key = r.x, wo = r.y, row = key & 0x7fffu, bit = key >> 15;
@@ -292,25 +317,18 @@ __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
           what = (sym_distance(((uint32_t)S ^ wo) & F20) <= a.k ? 1u : 0u) | (sym_distance(((uint32_t)(S >> 20) ^ wo) & F20) <= a.k ? 2u : 0u) |
                  (sym_distance(((uint32_t)(S >> 40) ^ wo) & F20) <= a.k ? 4u : 0u) | ((sl.y >> 31) ? WHAT_REST : 0u);
         }
-        pair_resolve(a, combo, rank, what, wo, (int64_t)(pw & 0xffffffffffull), &first, &have);
+        pair_resolve(a, vs, combo, rank, what, wo, (int64_t)(pw & 0xffffffffffull), &first, &have);
+      }
       }
     }
     if (a.debug & 16) have = false;
-    const unsigned long long bal = __ballot(have);
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    pair_emit(a, vs, have, first);                                  // (every lane is here)
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-      s_base = tot ? atomicAdd(a.counter, (unsigned long long)tot) : 0ull;
-    }
+    if (threadIdx.x == 0) s_full = s_fill > (uint32_t)(VSTAGE - 512);   // one thread decides: a wave that runs ahead into the next trip moves s_fill
     __syncthreads();
-    if (have) {
-      unsigned long long o = s_base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
-      for (int w = 0; w < wave; ++w) o += s_cnt[w];
-      if (o < a.cap) a.out[o] = first;
-    }
-    __syncthreads();                                                // s_cnt / s_base are rewritten by the next trip
+    if (s_full) flush();
   }
+  flush();
 }
 
 // One (field pair, chunk) of the scan.  A, B: key fields (compile time: every window offset of pass A is an
@@ -364,17 +382,39 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   // They are collected in a queue of this wave in LDS and leave in batches of >= 64, one atomic each
   // (same-address atomics serialise at ~2.5 ns; a dependent table read on this path held the whole
   // wave for a microsecond per suspect: 7 ms per 3 Gbp).
+  // The list's end is ONE counter for the whole grid, and same-address atomics serialise (~10 ns each under load): on a
+  // stream where a third of the windows are suspects (skewed composition, primers cut from the stream: 7e8 suspects per
+  // 300 Mbp) one atomic per batch of 64 was 1e7 atomics = the whole kernel (110 ms against 1.9 on uniform text).  So a
+  // wave that comes back for more reserves ahead: its first batch takes exactly what it holds (a wave of a uniform
+  // stream has 2.6 suspects in all: no unused slots), every later reservation doubles, up to 4096 slots; slots left
+  // over when the wave ends are marked (key all ones) and skipped by the verify kernel.
+  unsigned long long blk_at = 0;                                  // wave-uniform: next free slot of the wave's reserved run
+  uint32_t blk_left = 0, blk_next = 0;                            // slots left in it; size of the next reservation
   auto flush = [&]() __attribute__((always_inline)) {
-    if (qn == 0) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(a.susp_count, (unsigned long long)qn);
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
-    for (int e = lane; e < qn; e += 64) {
-      const u32x4 q = *lds128(QB + 16 * (uint32_t)e);
-      const uint64_t pw = (uint64_t)(ws + q.z) | ((uint64_t)combo << 40);
-      if (base + (unsigned long long)e < a.susp_cap) a.susp[base + (unsigned long long)e] = make_uint4(q.x, q.y, (uint32_t)pw, (uint32_t)(pw >> 32));
+    int done = 0;
+    while (done < qn) {
+      if (blk_left == 0) {
+        const uint32_t want = max((uint32_t)(qn - done), blk_next);
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.susp_count, (unsigned long long)want);
+        blk_at = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+        blk_left = want;
+        blk_next = min(2u * max(want, 64u), 4096u);
+      }
+      const int take = min(qn - done, (int)blk_left);
+      for (int e = lane; e < take; e += 64) {
+        const u32x4 q = *lds128(QB + 16 * (uint32_t)(done + e));
+        const uint64_t pw = (uint64_t)(ws + q.z) | ((uint64_t)combo << 40);
+        if (blk_at + (unsigned long long)e < a.susp_cap) a.susp[blk_at + (unsigned long long)e] = make_uint4(q.x, q.y, (uint32_t)pw, (uint32_t)(pw >> 32));
+      }
+      blk_at += (unsigned long long)take; blk_left -= (uint32_t)take; done += take;
     }
     qn = 0;
+  };
+  auto give_back = [&]() __attribute__((always_inline)) {          // the wave is done: mark what it reserved and did not use
+    for (uint32_t e = (uint32_t)lane; e < blk_left; e += 64)
+      if (blk_at + e < a.susp_cap) a.susp[blk_at + e] = make_uint4(0xffffffffu, 0, 0, 0);
+    blk_left = 0;
   };
   auto enqueue = [&](bool mine, uint32_t key, uint32_t wo, uint32_t prel) __attribute__((always_inline)) {
     const unsigned long long bal = __ballot(mine);
@@ -547,6 +587,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   for (int d = 0; d < NR / 2 + 1; ++d) two_rounds();                // and what is still in the pipeline
   if (keep == 0x9e3779b9u) a.susp[0] = make_uint4(keep, 0, 0, 0);   // (measurement switch: the verdicts must stay alive)
   flush();
+  give_back();
   if (stats) {
     for (int o = 32; o > 0; o >>= 1) st_hits += (uint32_t)__shfl_xor((int)st_hits, o);
     if (lane == 0) { atomicAdd(a.stats, (unsigned long long)st_blocks); atomicAdd(a.stats + 1, (unsigned long long)st_rounds); atomicAdd(a.stats + 2, (unsigned long long)st_hits); }
@@ -648,6 +689,7 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
   const size_t ST = (size_t)t.stride, KMAX = ST - 1;
   t.image.assign((size_t)C * PAIR_BITMAP_WORDS, 0);
   t.order.assign((size_t)C * np, 0);
+  t.olist.assign((size_t)C * np, 0);
   t.slots.assign((size_t)C * PAIR_BITMAP_WORDS * ST, 0);
   t.row_base.assign((size_t)C * (PAIR_BITMAP_WORDS + 1), 0);
   std::vector<std::vector<uint32_t>> fp(C);
@@ -665,6 +707,7 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
     std::sort(srt.begin(), srt.end());
     uint32_t *img = &t.image[(size_t)ci * PAIR_BITMAP_WORDS];
     uint32_t *ord = &t.order[(size_t)ci * np];
+    uint32_t *ol = &t.olist[(size_t)ci * np];
     uint64_t *slot = &t.slots[(size_t)ci * PAIR_BITMAP_WORDS * ST];
     uint32_t *rb = &t.row_base[(size_t)ci * (PAIR_BITMAP_WORDS + 1)];
     std::vector<uint32_t> &f = fp[ci];
@@ -683,6 +726,7 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
       for (size_t q = j; q < j2; ++q) {
         const uint32_t pi = (uint32_t)srt[q];
         ord[q] = pi;
+        ol[q] = field_of(t.pat40[pi], fc) | (field_of(t.pat40[pi], fd) << 10);
         if (q - j < 3) o[q - j] = field_of(t.pat40[pi], fc) | (field_of(t.pat40[pi], fd) << 10);
       }
       for (size_t q = j2 - j; q < 3; ++q) o[q] = o[0];               // free fields repeat the first pattern
@@ -721,6 +765,7 @@ hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
   if ((e = up(t.row_base.data(), t.row_base.size() * 4, (void **)&d->row_base)) != hipSuccess) return e;
   if ((e = up(t.first_pat.data(), t.first_pat.size() * 4, (void **)&d->first_pat)) != hipSuccess) return e;
   if ((e = up(t.order.data(), t.order.size() * 4, (void **)&d->order)) != hipSuccess) return e;
+  if ((e = up(t.olist.data(), t.olist.size() * 4, (void **)&d->olist)) != hipSuccess) return e;
   if ((e = up(t.pat40.data(), t.pat40.size() * 8, (void **)&d->pat40)) != hipSuccess) return e;
   if ((e = up(t.pat_len.data(), t.pat_len.size(), (void **)&d->pat_len)) != hipSuccess) return e;
   if ((e = up(t.pat_id.data(), t.pat_id.size() * 4, (void **)&d->pat_id)) != hipSuccess) return e;
@@ -735,7 +780,7 @@ hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st) {
 }
 
 void pair_free(PairDevice *d) {
-  void *ptrs[] = {d->image, d->slots, d->row_base, d->first_pat, d->order, d->pat_id, d->pat40, d->pat_len, d->pat_codes, d->pat_zone};
+  void *ptrs[] = {d->image, d->slots, d->row_base, d->first_pat, d->order, d->olist, d->pat_id, d->pat40, d->pat_len, d->pat_codes, d->pat_zone};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   *d = PairDevice();
 }
@@ -778,7 +823,7 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   a.debug = d.knobs.seed_debug;
   for (int c = 0; c < PAIR_MAX_COMBOS; ++c) { a.fa[c] = d.fa[c]; a.fb[c] = d.fb[c]; a.first_off[c] = (uint32_t)d.first_off[c]; }
   a.stride = d.stride;
-  a.image = d.image; a.slots = reinterpret_cast<const uint2 *>(d.slots); a.row_base = d.row_base; a.first_pat = d.first_pat; a.order = d.order;
+  a.image = d.image; a.slots = reinterpret_cast<const uint2 *>(d.slots); a.row_base = d.row_base; a.first_pat = d.first_pat; a.order = d.order; a.olist = d.olist;
   a.np = (uint32_t)d.np;
   a.pat40 = reinterpret_cast<const uint2 *>(d.pat40); a.pat_len = d.pat_len; a.pat_id = d.pat_id; a.pat_codes = d.pat_codes; a.pat_zone = d.pat_zone; a.viol_level = d.viol_level;
   a.out = d_out; a.counter = d_counter; a.cap = cap;

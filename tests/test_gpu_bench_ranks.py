@@ -82,3 +82,30 @@ def test_two_ranks_grow_and_rescan_after_overflow(tmp_path, k, indels):
     assert h1.size == h2.size and (h1 == h2).all()
     j3, h3 = run_bench(1, k, indels, str(tmp_path / "three.npy"), extra=("--capacity", "64"))
     assert j3["config"]["rescans_after_overflow"] >= 1 and (h1 == h3).all()
+
+
+@pytest.mark.parametrize("k,indels", [(2, 0), (2, 1)])
+def test_two_ranks_survive_a_chain_cut_by_the_guard_band(tmp_path, k, indels):
+    """a homopolymer run of 200,000 A's across the shard edge (the guard band is 64 Ki) with the primer
+    A x 20 in the set -- a chain of same-pattern candidates that no shard can decide on its own (filter_bitvec.cc:103-121:
+    one hit per chain).  The owned finalize says so (PM_E_UNSUPPORTED), the ranks tell each other through the count
+    exchange and take the gather-candidates form for that step, as GpuPatternMatch::sharded_scan does; the hits equal the
+    one-rank run's."""
+    extra = ("--plant-run", "200000", "--entries", "25")           # (25 entries: no end-of-sequence character at the shard edge, which would cut the run in two)
+    j1, h1 = run_bench(1, k, indels, str(tmp_path / "one.npy"), extra=extra)
+    j2, h2 = run_bench(2, k, indels, str(tmp_path / "two.npy"), extra=extra)
+    assert j2["config"]["steps_with_a_cut_chain"] == 3 and j1["config"]["steps_with_a_cut_chain"] == 0     # warmup + 2 steps
+    assert h1.size > 0 and h1.size == h2.size and (h1 == h2).all(), (h1.size, h2.size)
+    run = h1[h1["pid"] == PRIMERS]                                  # the poly-A primer (the last forward primer)
+    assert run.size == 1, run                                       # the whole run is ONE chain, one hit
+
+
+@pytest.mark.parametrize("style", ["skew", "vocab", "tandem"])
+def test_two_ranks_equal_one_rank_on_hard_streams(tmp_path, style):
+    """bench.py --stream-style: low-complexity streams (tests/adversarial.py's generators at database size), primers cut
+    from the stream; two position shards still give the one-rank hits (long chains, dense key hits, buffer growth)"""
+    extra = ("--stream-style", style, "--db-bases", "20000000", "--primers", "2000")
+    j1, h1 = run_bench(1, 2, 0, str(tmp_path / "one.npy"), extra=extra)
+    j2, h2 = run_bench(2, 2, 0, str(tmp_path / "two.npy"), extra=extra)
+    assert j1["config"]["stream_style"] == style
+    assert h1.size > 0 and h1.size == h2.size and (h1 == h2).all(), (style, h1.size, h2.size)
