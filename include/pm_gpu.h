@@ -242,6 +242,11 @@ int pm_last_kernel_time(pm_handle *h, float *ms, int *launches);
  * waves and field pairs.  n <= 8 values are written. */
 int pm_scan_stats(pm_handle *h, uint64_t *out, int n);
 
+/* Measurement helper (no reference counterpart; DESIGN.md 4.6 "pair geometry for edits"): on a -K 2 handle of the pair plan,
+ * time the 14-test pair geometry as the first stage of an edit-distance plan over the whole stream.  mode 1: substitution
+ * compare (lower bound), mode 2: five-shift edit test on two patterns per slot.  No hits are produced. */
+int pm_measure_pair_edit_floor(pm_handle *h, int mode, float *ms, uint64_t *suspects);
+
 /* Duration of the one-off re-encoding of the stream to 2 bits per base that pm_init[_device] runs
  * for the seed kernel family (0 for the bit-parallel family): not part of a scan, reported so that a
  * reader can add it to a single cold pass. */

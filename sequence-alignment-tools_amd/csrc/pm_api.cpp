@@ -61,6 +61,8 @@ struct pm_handle {
   SeedDevice sd;                      // first pattern tile (plan parameters are read from here)
   std::vector<SeedDevice> sd_more;    // further tiles when the pattern set is too large for one LDS filter
   std::vector<PairDevice> pair;       // -K 1 / -K 2 on 20..32 character patterns: the pair plan's tiles (pm_pair.hip) instead of sd
+  PairDevice epair;                   // -k 2 (filter_bitvec / shift_and_inexact): the pair geometry as the edit plan's first stage (one pattern tile)
+  bool epair_on = false;
   bool seed_flags = false;            // exact_halves on whole-pattern Hamming candidates (aux flags)
   bool bases_flags = false;           // exact_bases -K on whole-pattern Hamming candidates with clean exact zones (pair plan): records are final
   bool zoned = false;                 // some pattern has exact-base constraints
@@ -206,7 +208,7 @@ static void read_knobs(Knobs *k) {
   k->seed_tile = (long)num("PM_SEED_TILE");
   if (const char *v = getenv("PM_PAIR")) k->pair = atoi(v);
   k->pair_row = (int)num("PM_PAIR_ROW");
-  k->half_bloom = is("PM_HALF_SCAN", "bloom"); k->edit_bloom = is("PM_EDIT_SCAN", "bloom");
+  k->half_bloom = is("PM_HALF_SCAN", "bloom"); k->edit_bloom = is("PM_EDIT_SCAN", "bloom"); k->edit_hash = is("PM_EDIT_SCAN", "hash");
   k->edit_table_log = (int)num("PM_EDIT_TABLE_LOG");
   if (const char *v = getenv("PM_BITPAR_TP")) k->bitpar_tp = atoi(v) != 0;
   k->bitpar_seglen = num("PM_BITPAR_SEGLEN");
@@ -254,6 +256,7 @@ static void free_device(pm_handle *h) {
   h->sd_more.clear();
   for (PairDevice &d : h->pair) pair_free(&d);
   h->pair.clear();
+  pair_free(&h->epair); h->epair_on = false;
   if (h->d_cands) (void)hipFree(h->d_cands);
   { void *hx[] = {h->d_ext, h->d_half_codes, h->d_half_len, h->d_hesb, h->d_heeb, h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_seed_count, h->d_seeds, h->d_susp}; for (void *q : hx) if (q) (void)hipFree(q); }
   h->d_seed_count = nullptr; h->d_seeds = nullptr; h->d_susp = nullptr; h->susp_cap = 0;
@@ -477,6 +480,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
   h->sd_more.clear();
   for (PairDevice &d : h->pair) pair_free(&d);
   h->pair.clear();
+  pair_free(&h->epair); h->epair_on = false;
   // tables pm_finalize_device builds on first use depend on the alphabet mapping and the pattern
   // list of THIS init: drop the ones of an earlier init
   { void *lazy[] = {h->d_dp_codes, h->d_dp_esb, h->d_dp_eeb, h->d_fpat_len, h->d_fpat_id}; for (void *q : lazy) if (q) (void)hipFree(q); }
@@ -647,6 +651,18 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
       h->half_ranked_any = h->sd.half_ranked;
       for (const SeedDevice &d : h->sd_more) h->half_ranked_any = h->half_ranked_any || d.half_ranked;
       h->edits_dev = edits_mode;
+      // -k 2 on one pattern tile: the first stage runs on the PAIR geometry (pm_pair.hip, edit plan: 14 field-pair tests per
+      // window instead of 34 hashed piece triples; round 4) -- its tables are the substitution plan's with two patterns per
+      // slot, over the same pattern list as the automaton records of h->sd (seed records carry indices into it)
+      if (edits_mode && h->cfg.k == 2 && !h->bases_edits && h->sd_more.empty() && !h->knobs.edit_bloom && !h->knobs.edit_hash && !sp.empty()) {
+        PairTables pt;
+        const std::string msg = pair_build(sp, sid, h->alpha, 2, h->eos_code, &pt, h->knobs.pair_row, 2);
+        if (msg.empty()) {
+          HIP_TRY(h, pair_upload(pt, &h->epair, h->stream));
+          h->epair.knobs = h->knobs;
+          h->epair_on = true;
+        }
+      }
       if (halves_mode) {
         const size_t nh = h->inner.size();
         std::vector<uint8_t> codes(nh * 16, 0), lens(nh, 0);
@@ -864,7 +880,7 @@ extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
   }
   else if (h->kern == PM_KERNEL_SEED) {
     snprintf(buf, buflen, "kernel=%s tiles=%d combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
-             h->sd.edits && h->sd.edit_tabulated ? "pm_edit_scan+pm_edits_verify" : h->sd.edits ? "pm_seed_scan+pm_edits_verify" :
+             h->sd.edits && h->epair_on ? "pm_pair_edit_scan+pm_pair_edit_resolve+pm_edits_verify" : h->sd.edits && h->sd.edit_tabulated ? "pm_edit_scan+pm_edits_verify" : h->sd.edits ? "pm_seed_scan+pm_edits_verify" :
              h->sd.halves && h->sd.half_ranked ? "pm_half_scan+pm_half_verify" : "pm_seed_scan", 1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
              h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
     if (h->nrest) {
@@ -920,10 +936,22 @@ extern "C" int pm_scan_candidates_async(pm_handle *h, int64_t begin, int64_t end
         es.own_lo = h->own_begin; es.own_hi = h->own_end;
       }
       const SeedDevice &d = t == 0 ? h->sd : h->sd_more[t - 1];
-      HIP_TRY(h, seed_launch(d, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 ? &h->geo : nullptr, &es));
+      if (h->epair_on && h->edits_dev && t == 0) {
+        // first stage on the pair geometry: windows whose frame can hold an end in (begin, end] are the positions begin - 3 .. end + 1
+        const size_t want_susp = (size_t)((end - begin) / 10) + ((size_t)1 << 20);
+        if (!h->d_susp || h->susp_cap < want_susp) {
+          if (h->d_susp) { (void)hipFree(h->d_susp); h->d_susp = nullptr; }
+          h->susp_cap = std::max(h->susp_cap, want_susp);
+          HIP_TRY(h, hipMalloc(&h->d_susp, h->susp_cap * PAIR_SUSPECT_BYTES));
+        }
+        HIP_TRY(h, pair_launch(h->epair, h->d_text, h->d_packed, h->n, std::max<int64_t>(0, begin - 3), std::min<int64_t>(h->n, end + 2), h->d_cands, h->d_counter, h->cap,
+                               h->d_susp, h->d_seed_count + 260, h->susp_cap, h->stream, &h->geo, nullptr, 3, h->d_seeds, h->d_seed_count + 1, h->seed_cap));
+        es.skip_scan = true;
+      }
+      HIP_TRY(h, seed_launch(d, h->d_text, h->d_packed, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, t == 0 && !es.skip_scan ? &h->geo : nullptr, &es));
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    h->last_launches = 2 * ntiles;
+    h->last_launches = 2 * ntiles + (h->epair_on && h->edits_dev ? 1 : 0);
     if (h->nrest) { HIP_TRY(h, bitpar_launch(h->bp, h->d_text, h->n, begin, end, h->d_cands, h->d_counter, h->cap, h->stream, nullptr)); ++h->last_launches; }
   }
   else if (h->kern == PM_KERNEL_SEED && !h->pair.empty())
@@ -1268,6 +1296,12 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
       h->last_count = 0;
       return SCAN_AGAIN;
     }
+    if (h->epair_on && h->edits_dev && h->h_seed_count[260] > h->susp_cap) {   // the pair geometry's suspect list between its two kernels
+      (void)hipFree(h->d_susp); h->d_susp = nullptr;
+      h->susp_cap = (size_t)h->h_seed_count[260] + (size_t)h->h_seed_count[260] / 8 + 1024;
+      h->last_count = 0;
+      return SCAN_AGAIN;
+    }
   }
   if (h->halves_dev) {
     // second device pass: banded DP next to every surviving seed (pm_extend.hip); the records
@@ -1435,6 +1469,37 @@ extern "C" int pm_scan_stats(pm_handle *h, uint64_t *out, int n) {
   }
   v[2] = h->internal_rescans;
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return PM_OK;
+}
+
+// Measurement (no reference counterpart): time the pair geometry as the FIRST STAGE of an edit-distance
+// plan on this handle's tables -- a -K 2 handle on the pair plan -- over the whole stream: 14 (field pair, displacement)
+// tests per window (scripts/edit_pair_cover.py), mode 1 = with the substitution compare (a lower bound of such a kernel),
+// mode 2 = with the five-shift necessary condition for "<= 2 edits on the other ten bases" on two patterns per slot.
+// Produces no hits: *ms is the kernel's duration, *suspects the records it would hand to a verify kernel.
+extern "C" int pm_measure_pair_edit_floor(pm_handle *h, int mode, float *ms, uint64_t *suspects) {
+  if (!h || !h->inited || !ms || !suspects || (mode != 1 && mode != 2)) return fail(h, PM_E_INVALID, "pm_measure_pair_edit_floor: bad arguments");
+  if (h->kern != PM_KERNEL_SEED || h->pair.size() != 1 || h->cfg.k != 2 || h->cfg.indels)
+    return fail(h, PM_E_UNSUPPORTED, "pm_measure_pair_edit_floor: needs a -K 2 handle on the pair plan (one pattern tile)");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  drain_spec(h);
+  const size_t want = (size_t)(h->n / 16) + ((size_t)1 << 20);
+  if (!h->d_susp || h->susp_cap < want) {
+    if (h->d_susp) { (void)hipFree(h->d_susp); h->d_susp = nullptr; }
+    h->susp_cap = want;
+    HIP_TRY(h, hipMalloc(&h->d_susp, h->susp_cap * PAIR_SUSPECT_BYTES));
+  }
+  if (!h->d_seed_count) HIP_TRY(h, hipMalloc((void **)&h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMemsetAsync(h->d_seed_count, 0, SEEDCOUNT_WORDS * sizeof(unsigned long long), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  HIP_TRY(h, pair_launch(h->pair[0], h->d_text, h->d_packed, h->n, 0, h->n, h->d_cands, h->d_counter, h->cap, h->d_susp, h->d_seed_count + 1, h->susp_cap,
+                         h->stream, nullptr, nullptr, mode));
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->h_seed_count, h->d_seed_count, SEEDCOUNT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  (void)hipEventElapsedTime(ms, h->ev0, h->ev1);
+  *suspects = h->h_seed_count[1];
   return PM_OK;
 }
 

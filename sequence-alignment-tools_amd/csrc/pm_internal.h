@@ -40,6 +40,7 @@ struct Knobs {
   int pair_row = 0;                  // PM_PAIR_ROW: slots per row of the pair plan's slot table (measurement)
   bool half_bloom = false;           // exact_halves -k on the round-1 form (PM_HALF_SCAN=bloom)
   bool edit_bloom = false;           // edits: first stage = the round-1 pm_seed_scan instance (PM_EDIT_SCAN=bloom)
+  bool edit_hash = false;            // edits: first stage = round 2's pm_edit_scan (PM_EDIT_SCAN=hash) where the pair geometry would run (-k 2, one tile)
   int edit_table_log = 0;            // edits: log2 of the key map's bits
   int bitpar_tp = -1;                // force the text-parallel (1) / tile (0) form of the bit-parallel kernel
   long long bitpar_seglen = 0;

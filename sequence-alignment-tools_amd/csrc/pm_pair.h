@@ -61,7 +61,7 @@ struct PairDevice {
 // "" or why the plan does not take this pattern set
 // stride_knob: slots per row of the slot table (0 = default)
 std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids, const Alphabet &alpha, int k,
-                       int eos_code, PairTables *out, int stride_knob = 0);
+                       int eos_code, PairTables *out, int stride_knob = 0, int slot_patterns = 3);
 hipError_t pair_upload(const PairTables &t, PairDevice *d, hipStream_t st);
 void pair_free(PairDevice *d);
 ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end);
@@ -71,6 +71,10 @@ ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end);
 constexpr size_t PAIR_SUSPECT_BYTES = 16;
 hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, void *d_susp, unsigned long long *d_susp_count, uint64_t susp_cap,
-                       hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats = nullptr);
+                       hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats = nullptr, int floor_mode = 0,
+                       uint64_t *seed_out = nullptr, unsigned long long *seed_count = nullptr, uint64_t seed_cap = 0);
+// floor_mode 3 = the edit-distance plan on the pair geometry (-k 2): pm_pair_floor<3> (14 tests per window, edit_cost) +
+// pm_pair_edit_resolve, seed records (pattern index << 40 | position) into seed_out for pm_edits_verify; tables built
+// with slot_patterns = 2.  floor_mode 1, 2: measurement kernels (pm_measure_pair_edit_floor).
 
 }  // namespace pm

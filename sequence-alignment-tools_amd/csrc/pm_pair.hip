@@ -99,6 +99,9 @@ struct PairArgs {
   uint4 *susp;                          // suspect records for pm_pair_verify: {key, other fields, position | combo << 40}
   unsigned long long *susp_count;
   unsigned long long susp_cap;
+  uint64_t *seed_out;                   // edit plan (pm_pair_edit_resolve): 8-byte seed records pattern index << 40 | position for pm_edits_verify
+  unsigned long long *seed_count;
+  unsigned long long seed_cap;
   unsigned long long *stats;            // measurement (debug & 32): [0] blocks of 1024 positions, [1] rounds, [2] key hits, over waves and field pairs
 };
 
@@ -147,6 +150,131 @@ __device__ __host__ __forceinline__ void other_fields(int a, int b, int *c, int 
   for (int j = 0; j < 4; ++j) if (j != a && j != b) o[t++] = j;
   *c = o[0]; *d = o[1];
 }
+
+
+// ---- edit distance on the pair geometry -------------------------------------------------------
+// A match with <= 2 edits (substitution, insertion, deletion) of a pattern's last 20 bases leaves two of the four fields
+// untouched; they sit in the text 5 (B - A) + d bases apart, d = net insertions between them, |d| <= 2.  14 tests
+// (A, B, d) cover every placement of two edits (scripts/edit_pair_cover.py).  A key hit of test (A, B, d) fixes a frame --
+// field B where the window has it, field A displaced by -d -- and what remains is a decision about the OTHER ten bases:
+// can they be brought to the text with the edits that are left?  `edit_cost` is a necessary condition for that, cheap enough
+// to run for every key hit; the automaton (pm_edits_verify, shift_and_inexact.cc:249-352) decides exactly afterwards.
+//
+// In the frame, pattern base j sits at text base j + s(j).  s = 0 on field B and -d on field A; an insertion raises s by one
+// for the bases behind it (towards the pattern's end), a deletion lowers it and leaves the deleted base without a partner, a
+// substitution leaves one base without a partner.  The other fields fall into regions: L (in front of A), M (between A and
+// B), R (behind B).  Within a region with i insertions and e deletions the bases take i + e + 1 consecutive shifts, and at
+// most (substitutions + e) of them match at none of those shifts.  So, ORDER IGNORED (which only lets more through):
+//     edits in the region >= i + max(e, u),   u = bases of the region that match at no shift of the set,
+// minimised over the shift sets the remaining budget allows, and the regions' minima add up (the budget is one sum).
+// Mixed sets (an insertion and a deletion in one region) are dominated by the one-sided sets of the same span.
+//   R, base shift 0:            {0}: u | {0,+1}: 1 + u | {0,-1}: max(1, u) | {0,+1,+2}: 2 + u | {0,-1,-2}: max(2, u)
+//   L, base shift -d (mirror):  {0}: u | {+1}: max(1, u) | {-1}: 1 + u | {+1,+2}: max(2, u) | {-1,-2}: 2 + u   (relative to -d)
+//   M, from -d at A to 0 at B:  d = 0: u | 1 + max(1, u{0,+1}) | 1 + max(1, u{0,-1});  d = 1: 1 + u{-1,0};  d = -1: max(1, u{1,0});
+//                               d = 2: 2 + u{-2,-1,0};  d = -2: max(2, u{2,1,0})
+// Window bits: base t of the text, t = -2 .. 21 relative to the 20-base window whose last base is the lane's position, at bits
+// 2 (t + 2) of whi : wlo (2 bits per base; N and end-of-sequence alias to a base there, which only lets more through).
+template <int OFF>
+__device__ __forceinline__ uint32_t wbits(uint32_t wlo, uint32_t whi) {
+  static_assert(OFF >= 0 && OFF < 48, "window offset");
+  if constexpr (OFF == 0) return wlo;
+  else if constexpr (OFF < 32) return __builtin_amdgcn_alignbit(whi, wlo, OFF);
+  else return whi >> (OFF - 32);
+}
+// one flag per base (even bit positions): NB pattern bases p against the text bases T .. T + NB - 1
+template <int NB, int T>
+__device__ __forceinline__ uint32_t mism(uint32_t p, uint32_t wlo, uint32_t whi) {
+  static_assert(T >= -2 && T + NB <= 22, "text base outside the window");
+  const uint32_t x = p ^ wbits<2 * (T + 2)>(wlo, whi);
+  return (x | (x >> 1)) & (NB == 5 ? 0x155u : 0x55555u);
+}
+enum { REG_L = 0, REG_M = 1, REG_R = 2 };
+// cost of one region: NB bases from pattern base T0 on, base shift BASE, remaining budget BUDGET (shift sets that need more
+// indels than that are not tried -- they would also reach outside the window)
+template <int KIND, int NB, int T0, int BASE, int DSP, int BUDGET>
+__device__ __forceinline__ int region_cost(uint32_t p, uint32_t wlo, uint32_t whi) {
+  const uint32_t m0 = mism<NB, T0 + BASE>(p, wlo, whi);
+  if constexpr (KIND == REG_M) {
+    if constexpr (DSP == 0) {
+      int c = __popc(m0);
+      if constexpr (BUDGET >= 2) {
+        const int up = 1 + max(1, __popc(m0 & mism<NB, T0 + 1>(p, wlo, whi))), dn = 1 + max(1, __popc(m0 & mism<NB, T0 - 1>(p, wlo, whi)));
+        c = min(c, min(up, dn));
+      }
+      return c;
+    }
+    else if constexpr (DSP == 1) return 1 + __popc(m0 & mism<NB, T0 - 1>(p, wlo, whi));
+    else if constexpr (DSP == -1) return max(1, __popc(m0 & mism<NB, T0 + 1>(p, wlo, whi)));
+    else if constexpr (DSP == 2) return 2 + __popc(m0 & mism<NB, T0 - 1>(p, wlo, whi) & mism<NB, T0 - 2>(p, wlo, whi));
+    else return max(2, __popc(m0 & mism<NB, T0 + 1>(p, wlo, whi) & mism<NB, T0 + 2>(p, wlo, whi)));
+  } else {
+    // R: +1 = insertion, -1 = deletion; L (scanned away from A, towards the pattern's start): +1 = deletion, -1 = insertion
+    int c = __popc(m0);
+    if constexpr (BUDGET >= 1) {
+      const uint32_t mp1 = m0 & mism<NB, T0 + BASE + 1>(p, wlo, whi), mn1 = m0 & mism<NB, T0 + BASE - 1>(p, wlo, whi);
+      const int up = __popc(mp1), dn = __popc(mn1);
+      c = min(c, KIND == REG_R ? min(1 + up, max(1, dn)) : min(max(1, up), 1 + dn));
+      if constexpr (BUDGET >= 2) {
+        const int up2 = __popc(mp1 & mism<NB, T0 + BASE + 2>(p, wlo, whi)), dn2 = __popc(mn1 & mism<NB, T0 + BASE - 2>(p, wlo, whi));
+        c = min(c, KIND == REG_R ? min(2 + up2, max(2, dn2)) : min(max(2, up2), 2 + dn2));
+      }
+    }
+    return c;
+  }
+}
+// lower bound of the edits a match of test (A, B, DSP) needs on the two fields outside the key, o = their 20 pattern bits
+// (lower field in bits 0..9); <= 2 - |DSP|... the forced indels are part of region M's cost: a candidate needs edit_cost <= 2
+template <int A, int B, int DSP>
+__device__ __forceinline__ int edit_cost(uint32_t o, uint32_t wlo, uint32_t whi) {
+  constexpr int C = (A != 0 && B != 0) ? 0 : ((A != 1 && B != 1) ? 1 : 2);
+  constexpr int D = (A != 3 && B != 3) ? 3 : ((A != 2 && B != 2) ? 2 : 1);
+  constexpr int AD = DSP < 0 ? -DSP : DSP, BUD = 2 - AD;
+  static_assert(B > A + 1 || DSP == 0, "adjacent key fields are not displaced");
+  if constexpr (A == 0 && B == 1) return region_cost<REG_R, 10, 10, 0, 0, BUD>(o, wlo, whi);                       // fields 2, 3 behind B
+  else if constexpr (A == 2 && B == 3) return region_cost<REG_L, 10, 0, 0, 0, BUD>(o, wlo, whi);                   // fields 0, 1 in front of A
+  else if constexpr (A == 0 && B == 3) return region_cost<REG_M, 10, 5, 0, DSP, BUD>(o, wlo, whi);                 // fields 1, 2 between
+  else if constexpr (A == 1 && B == 2) {                                                                            // field 0 in front, field 3 behind
+    const int cl = region_cost<REG_L, 5, 0, 0, 0, BUD>(o, wlo, whi);
+    return cl + region_cost<REG_R, 5, 15, 0, 0, BUD>(o >> 10, wlo, whi);
+  }
+  else if constexpr (A == 0 && B == 2) {                                                                            // field 1 between, field 3 behind
+    const int cm = region_cost<REG_M, 5, 5, 0, DSP, BUD>(o, wlo, whi);
+    return cm + region_cost<REG_R, 5, 15, 0, 0, BUD>(o >> 10, wlo, whi);
+  }
+  else {                                                                                                            // (1, 3): field 0 in front of A (shift -DSP), field 2 between
+    static_assert(A == 1 && B == 3 && C == 0 && D == 2, "fields");
+    const int cl = region_cost<REG_L, 5, 0, -DSP, 0, BUD>(o, wlo, whi);
+    return cl + region_cost<REG_M, 5, 10, 0, DSP, BUD>(o >> 10, wlo, whi);
+  }
+}
+// the 20-bit key of test (A, B, DSP) from the window's 48 bits (field B in place, field A displaced by -DSP bases)
+template <int A, int B, int DSP>
+__device__ __forceinline__ uint32_t edit_key(uint32_t wlo, uint32_t whi) {
+  return (wbits<4 + 10 * A - 2 * DSP>(wlo, whi) & 0x3ffu) | ((wbits<4 + 10 * B>(wlo, whi) & 0x3ffu) << 10);
+}
+// the 14 tests in table order; f(integral constants A, B, DSP) is called for variant v
+template <typename F>
+__device__ __forceinline__ void edit_variant(int v, F &&f) {
+  using std::integral_constant;
+  switch (v) {
+    case 0: f(integral_constant<int, 0>(), integral_constant<int, 1>(), integral_constant<int, 0>()); break;
+    case 1: f(integral_constant<int, 0>(), integral_constant<int, 2>(), integral_constant<int, -1>()); break;
+    case 2: f(integral_constant<int, 0>(), integral_constant<int, 2>(), integral_constant<int, 0>()); break;
+    case 3: f(integral_constant<int, 0>(), integral_constant<int, 2>(), integral_constant<int, 1>()); break;
+    case 4: f(integral_constant<int, 0>(), integral_constant<int, 3>(), integral_constant<int, -2>()); break;
+    case 5: f(integral_constant<int, 0>(), integral_constant<int, 3>(), integral_constant<int, -1>()); break;
+    case 6: f(integral_constant<int, 0>(), integral_constant<int, 3>(), integral_constant<int, 0>()); break;
+    case 7: f(integral_constant<int, 0>(), integral_constant<int, 3>(), integral_constant<int, 1>()); break;
+    case 8: f(integral_constant<int, 0>(), integral_constant<int, 3>(), integral_constant<int, 2>()); break;
+    case 9: f(integral_constant<int, 1>(), integral_constant<int, 2>(), integral_constant<int, 0>()); break;
+    case 10: f(integral_constant<int, 1>(), integral_constant<int, 3>(), integral_constant<int, -1>()); break;
+    case 11: f(integral_constant<int, 1>(), integral_constant<int, 3>(), integral_constant<int, 0>()); break;
+    case 12: f(integral_constant<int, 1>(), integral_constant<int, 3>(), integral_constant<int, 1>()); break;
+    case 13: f(integral_constant<int, 2>(), integral_constant<int, 3>(), integral_constant<int, 0>()); break;
+    default: break;
+  }
+}
+__device__ __host__ __forceinline__ int edit_variant_table(int var) { return var == 0 ? 0 : (var <= 3 ? 1 : (var <= 8 ? 2 : (var == 9 ? 3 : (var <= 12 ? 4 : 5)))); }
 
 // Exact part of the verify (second kernel): (window ending at p, pattern pi) agree on this combo's key
 // and are within k substitutions on the rest of the packed window; count mismatches on the raw stream
@@ -337,8 +465,18 @@ __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
 // ring of register entries: pick the window and re-read its bitmap row; rank in the row, slot address, 8-byte
 // load; compare the slot's three patterns).  What the compare cannot dismiss (1e-3 of the windows) is queued in LDS
 // and leaves in batches for pm_pair_verify.  See the file comment and the comments at the stages.
-template <int A, int B>
-__device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int combo, const int cj) {
+template <typename F>
+__device__ __forceinline__ void static_for5(F &&f) { for_windows(std::make_integer_sequence<int, 5>(), f); }
+
+// DSP, FLOOR: measurement instantiations (pm_pair_floor below): the pair geometry as the first stage of an
+// EDIT-distance plan tests field A displaced by DSP bases against field B (two clean fields of a match with <= 2 edits sit
+// 5 (B - A) + d bases apart, |d| <= 2; 14 (pair, d) tests cover every placement, scripts/edit_pair_cover.py).  FLOOR = 1
+// keeps the substitution compare of the slot's three patterns (a lower bound of such a kernel's cost), FLOOR = 2 runs, for
+// two patterns of the slot, the cheapest necessary condition for "<= 2 edits on the other ten bases" that was found: mismatch
+// masks at five shifts, tiered AND / popcount tests.  Neither produces a hit list: they exist to be timed.  With DSP = 0 and
+// FLOOR = 0 (the product's instantiations) every `if constexpr` below takes the branch that was there before.
+template <int A, int B, int DSP = 0, int FLOOR = 0>
+__device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int combo, const int cj, const int variant = 0) {
   constexpr int C = (A != 0 && B != 0) ? 0 : ((A != 1 && B != 1) ? 1 : 2);
   constexpr int D = (A != 3 && B != 3) ? 3 : ((A != 2 && B != 2) ? 2 : 1);
   static_assert(A < B && C < D && C != A && C != B && D != A && D != B, "fields");
@@ -367,10 +505,12 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t keep = 0;                                              // measurement (debug & 1): verdicts folded, never emitted
 
   // four blocks of 1024 bases (one packed dword per lane each) in flight per wave
+  // (the edit plan's windows look two bases beyond themselves: its waves also fetch the block behind their range)
+  const int64_t pre_hi = FLOOR == 3 ? own_hi + 1024 : own_hi;
   uint32_t q0 = load_packed(a.packed, a.npacked, ws + 16 * lane);
-  uint32_t q1 = ws + 1024 < own_hi ? load_packed(a.packed, a.npacked, ws + 1024 + 16 * lane) : 0u;
-  uint32_t q2 = ws + 2048 < own_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
-  uint32_t q3 = ws + 3072 < own_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
+  uint32_t q1 = ws + 1024 < pre_hi ? load_packed(a.packed, a.npacked, ws + 1024 + 16 * lane) : 0u;
+  uint32_t q2 = ws + 2048 < pre_hi ? load_packed(a.packed, a.npacked, ws + 2048 + 16 * lane) : 0u;
+  uint32_t q3 = ws + 3072 < pre_hi ? load_packed(a.packed, a.npacked, ws + 3072 + 16 * lane) : 0u;
   const uint32_t *pk_wave = a.packed + (ws >> 4);                 // wave-uniform: the wave's first dword (ws is a multiple of 1024)
   uint32_t pf_idx = 4096u / 16u + (uint32_t)lane;                  // dword of this lane in the block four ahead
 
@@ -404,7 +544,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       const int take = min(qn - done, (int)blk_left);
       for (int e = lane; e < take; e += 64) {
         const u32x4 q = *lds128(QB + 16 * (uint32_t)(done + e));
-        const uint64_t pw = (uint64_t)(ws + q.z) | ((uint64_t)combo << 40);
+        const uint64_t pw = (uint64_t)(ws + q.z) | ((uint64_t)(FLOOR == 3 ? variant : combo) << 40);
         if (blk_at + (unsigned long long)e < a.susp_cap) a.susp[blk_at + (unsigned long long)e] = make_uint4(q.x, q.y, (uint32_t)pw, (uint32_t)(pw >> 32));
       }
       blk_at += (unsigned long long)take; blk_left -= (uint32_t)take; done += take;
@@ -413,7 +553,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   };
   auto give_back = [&]() __attribute__((always_inline)) {          // the wave is done: mark what it reserved and did not use
     for (uint32_t e = (uint32_t)lane; e < blk_left; e += 64)
-      if (blk_at + e < a.susp_cap) a.susp[blk_at + e] = make_uint4(0xffffffffu, 0, 0, 0);
+      if (blk_at + e < a.susp_cap) a.susp[blk_at + e] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     blk_left = 0;
   };
   auto enqueue = [&](bool mine, uint32_t key, uint32_t wo, uint32_t prel) __attribute__((always_inline)) {
@@ -434,8 +574,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   // window I starts at bit 2 I + 26 of prev2 : prev1 : cur; field f at + 10 f.  The key comes out at bits 2..21.
   auto key_of = [&](auto WIN, uint32_t prev2, uint32_t prev1, uint32_t cur) __attribute__((always_inline)) -> uint32_t {
     constexpr int I = decltype(WIN)::value;
-    const uint32_t X = bits_at<2 * I + 26 + 10 * A - 2>(prev2, prev1, cur);
-    if constexpr (B == A + 1) return X;
+    const uint32_t X = bits_at<2 * I + 26 + 10 * A - 2 - 2 * DSP>(prev2, prev1, cur);
+    if constexpr (B == A + 1 && DSP == 0) return X;
     else { const uint32_t Y = bits_at<2 * I + 26 + 10 * B - 12>(prev2, prev1, cur); return (X & 0xffcu) | (Y & ~0xffcu); }
   };
 
@@ -471,6 +611,8 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   uint32_t tagbase = 0xfffffff0u;                                   // 16 (block - 1): a pending window's tag = tagbase + i = 16 x its block + its index in the block
   u32x2 e_sl[NR];                                                   // slot
   uint32_t e_key[NR], e_wo[NR], e_rel[NR], e_okm[NR], e_wd[NR];       // key, other fields, position, validity (sign bit), the key's row of the bitmap
+  uint32_t e_hi[FLOOR >= 2 ? NR : 1];                                // (FLOOR 2, 3: e_wo / e_hi = the window's 48 bits from two bases in front of it)
+  for (int d = 0; d < (FLOOR >= 2 ? NR : 1); ++d) e_hi[d] = 0;
 #pragma unroll
   for (int d = 0; d < NR; ++d) { e_sl[d].x = 0; e_sl[d].y = 0; e_key[d] = e_wo[d] = e_rel[d] = e_okm[d] = e_wd[d] = 0; }
   uint32_t m5v, f20v, rowmask;                                      // constants in VGPRs: an SGPR or literal operand halves the issue rate of v_and
@@ -481,7 +623,31 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     // stage 3: entry PH, whose slot was loaded NR - 1 rounds ago: substitutions against each of the slot's three
     // patterns minus k + 1, a negative one = within k; the slot's "walk" flag is the sign bit of its high dword;
     // any sign bit = suspicious (if the entry holds a window at all)
-    {
+    if constexpr (FLOOR == 3) {
+      // the slot's two patterns (the table of the edit plan holds two per key; more: walk flag): can the other ten bases be
+      // brought to the text with the edits that are left?  cost - 3 < 0 = yes as far as edit_cost can tell
+      const uint32_t lo = e_wo[PH], hi = e_hi[PH];
+      const int d1 = edit_cost<A, B, DSP>(e_sl[PH].x & f20v, lo, hi) - 3;
+      const int d2 = edit_cost<A, B, DSP>(__builtin_amdgcn_alignbit(e_sl[PH].y, e_sl[PH].x, 20) & f20v, lo, hi) - 3;
+      const bool susp = (int)(((uint32_t)(d1 | d2) | e_sl[PH].y) & e_okm[PH]) < 0;
+      enqueue(susp, lo, hi, ((e_rel[PH] >> 4) << 10) + 16u * (uint32_t)lane + (e_rel[PH] & 15u));
+    } else if constexpr (FLOOR == 2) {
+      // the other ten pattern bases (contiguous from field C in this cost model) against the text at shifts -2 .. 2
+      constexpr int OC = 4 + 10 * C;
+      const uint32_t lo = e_wo[PH], hi = e_hi[PH];
+      uint32_t T[5];
+      static_for5([&](auto SI) __attribute__((always_inline)) { constexpr int si = decltype(SI)::value; T[si] = __builtin_amdgcn_alignbit(hi, lo, OC + 2 * (si - 2)) & f20v; });
+      auto score = [&](uint32_t o) __attribute__((always_inline)) -> int {
+        uint32_t m[5];
+        static_for5([&](auto SI) __attribute__((always_inline)) { constexpr int si = decltype(SI)::value; const uint32_t x = o ^ T[si]; m[si] = (x | (x >> 1)) & m5v; });
+        const int c0 = __popc(m[2]), c1 = __popc(m[2] & m[3]) + 1, c1n = __popc(m[2] & m[1]) + 1;
+        const int c2 = __popc(m[2] & m[3] & m[4]) + 2, c2n = __popc(m[2] & m[1] & m[0]) + 2;
+        return min(min(c0, min(c1, c1n)), min(c2, c2n)) - 3;          // negative = within two edits as far as this test can tell
+      };
+      const int d1 = score(e_sl[PH].x & f20v), d2 = score(__builtin_amdgcn_alignbit(e_sl[PH].y, e_sl[PH].x, 20) & f20v);
+      const bool susp = (int)(((uint32_t)(d1 | d2) | e_sl[PH].y) & e_okm[PH]) < 0;
+      enqueue(susp, e_key[PH], lo, ((e_rel[PH] >> 4) << 10) + 16u * (uint32_t)lane + (e_rel[PH] & 15u));
+    } else {
       const uint32_t w = e_wo[PH];
       const uint32_t x1 = e_sl[PH].x ^ w, x2 = __builtin_amdgcn_alignbit(e_sl[PH].y, e_sl[PH].x, 20) ^ w, x3 = (e_sl[PH].y >> 8) ^ w;
       const int d1 = __popc((x1 | (x1 >> 1)) & m5v) + negk1;
@@ -512,8 +678,16 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
       // 20 bits from window bit O (O = 0, 10, 20; junk above bit 19 unless masked)
       auto from = [&](int O) __attribute__((always_inline)) -> uint32_t { return O == 0 ? wlo : (O == 10 ? wlo >> 10 : __builtin_amdgcn_alignbit(whi, wlo, 20)); };
       uint32_t key, wo;
+      if constexpr (FLOOR != 0) {
+        // (measurement builds: the block's words start two bases in front of the window, see cu1 below; field A displaced)
+        constexpr int OA = 4 + 10 * A - 2 * DSP, OB = 4 + 10 * B - 10, OCC = 4 + 10 * C, ODD = 4 + 10 * D - 10;
+        key = (__builtin_amdgcn_alignbit(whi, wlo, OA) & 0x3ffu) | (__builtin_amdgcn_alignbit(whi, wlo, OB) & 0xffc00u);
+        if constexpr (FLOOR >= 2) { wo = wlo; e_hi[PH] = whi; }
+        else wo = (__builtin_amdgcn_alignbit(whi, wlo, OCC) & 0x3ffu) | (__builtin_amdgcn_alignbit(whi, wlo, ODD) & 0xffc00u);
+      } else {
       if constexpr (B == A + 1) key = from(10 * A) & f20v; else key = (from(10 * A) & 0x3ffu) | (from(10 * B - 10) & 0xffc00u);
       if constexpr (D == C + 1) wo = from(10 * C) & f20v; else wo = (from(10 * C) & 0x3ffu) | (from(10 * D - 10) & 0xffc00u);
+      }
       key &= (uint32_t)((int)okm >> 31);                              // no window: key 0 (row 0: one cached line)
       e_key[PH] = key; e_wo[PH] = wo; e_okm[PH] = okm;
       e_rel[PH] = tagbase + i;
@@ -541,7 +715,7 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
   while (bb < own_hi) {
     const uint32_t cur = q0;
     q0 = q1; q1 = q2; q2 = q3;
-    if (bb + 4096 < own_hi) q3 = pk_wave[pf_idx];                    // (the packed stream is padded: no per-lane bounds check)
+    if (bb + 4096 < pre_hi) q3 = pk_wave[pf_idx];                    // (the packed stream is padded: no per-lane bounds check)
     pf_idx += 64u;
     // the two dwords in front of every lane's own: whole-wave shifts by one lane (lane 0 takes the carry)
     const uint32_t prev1 = __builtin_amdgcn_update_dpp(carry1, cur, 0x138, 0xf, 0xf, false);       // wave_shr:1
@@ -571,7 +745,15 @@ __device__ __forceinline__ void pair_scan_body(const PairArgs &a, const int comb
     }
     P |= acc & (own << 16);
     if (stats) { st_hits += (uint32_t)__popc(acc & (own << 16)); ++st_blocks; }
-    cu1 = __builtin_amdgcn_alignbit(prev1, prev2, 26); cu2 = __builtin_amdgcn_alignbit(cur, prev1, 26); cu3 = cur >> 26;
+    constexpr int WB = FLOOR != 0 ? 22 : 26;                          // (measurement builds keep two more bases in front of the windows)
+    cu1 = __builtin_amdgcn_alignbit(prev1, prev2, WB); cu2 = __builtin_amdgcn_alignbit(cur, prev1, WB); cu3 = cur >> WB;
+    if constexpr (FLOOR == 3) {
+      // a lane's last windows reach two bases into the next lane's dword (shifts + 1, + 2 behind the window): whole-wave
+      // shift the other way, lane 63 takes the next block's first dword (prefetched: q0 already is the next block)
+      const uint32_t nfirst = __builtin_amdgcn_readfirstlane(q0);
+      const uint32_t nxt = __builtin_amdgcn_update_dpp(nfirst, cur, 0x130, 0xf, 0xf, false);       // wave_shl:1
+      cu3 |= nxt << 10;
+    }
     // pass B (skipped while no lane has a hit pending and the pipeline has run empty: sparse pattern sets)
     if (__ballot(P != 0)) quiet = 0;
     if (quiet <= NR) {
@@ -629,12 +811,150 @@ __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_scan(PairArgs a) {
   }
 }
 
+// The pair geometry as the first stage of the edit-distance plan: 14 (field pair, displacement) tests per window, one
+// workgroup per (test, chunk), the tests of one field pair next to each other in the grid (they share that pair's slot
+// table in L2).  FLOOR = 3 is the product (-k 2: edit_cost, suspects for pm_pair_edit_resolve); FLOOR = 1, 2 are the
+// measurement builds the plan was decided on (profiles/r04_edit_pair_floor.json): they write suspect records and nothing
+// else.  a.ncombos = 14.
+template <int FLOOR>
+__global__ __launch_bounds__(PAIR_THREADS) void pm_pair_floor(PairArgs a) {
+  extern __shared__ uint32_t lds[];
+  const int per_super = a.group * a.ncombos;
+  const int sc = blockIdx.x / per_super;
+  const int rem = blockIdx.x - sc * per_super;
+  int var = rem / a.group;
+  int cj = sc * a.group + (rem - var * a.group);
+  const int full = (a.nchunks / a.group) * a.group;
+  if (sc * a.group >= full) {
+    const int tail = a.nchunks - full;
+    const int r2 = blockIdx.x - (full / a.group) * per_super;
+    var = r2 / tail;
+    cj = full + (r2 - var * tail);
+  }
+  if (cj >= a.nchunks || var >= a.ncombos) return;
+  // variants in table order: (0,1,0); (0,2,-1..1); (0,3,-2..2); (1,2,0); (1,3,-1..1); (2,3,0)
+  const int table = edit_variant_table(var);
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(a.image + (size_t)table * PAIR_BITMAP_WORDS);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+    for (int i = threadIdx.x; i < PAIR_BITMAP_WORDS / 4; i += PAIR_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  switch (var) {                                                    // wave-uniform
+    case 0: pair_scan_body<0, 1, 0, FLOOR>(a, table, cj, 0); break;
+    case 1: pair_scan_body<0, 2, -1, FLOOR>(a, table, cj, 1); break;
+    case 2: pair_scan_body<0, 2, 0, FLOOR>(a, table, cj, 2); break;
+    case 3: pair_scan_body<0, 2, 1, FLOOR>(a, table, cj, 3); break;
+    case 4: pair_scan_body<0, 3, -2, FLOOR>(a, table, cj, 4); break;
+    case 5: pair_scan_body<0, 3, -1, FLOOR>(a, table, cj, 5); break;
+    case 6: pair_scan_body<0, 3, 0, FLOOR>(a, table, cj, 6); break;
+    case 7: pair_scan_body<0, 3, 1, FLOOR>(a, table, cj, 7); break;
+    case 8: pair_scan_body<0, 3, 2, FLOOR>(a, table, cj, 8); break;
+    case 9: pair_scan_body<1, 2, 0, FLOOR>(a, table, cj, 9); break;
+    case 10: pair_scan_body<1, 3, -1, FLOOR>(a, table, cj, 10); break;
+    case 11: pair_scan_body<1, 3, 0, FLOOR>(a, table, cj, 11); break;
+    case 12: pair_scan_body<1, 3, 1, FLOOR>(a, table, cj, 12); break;
+    case 13: pair_scan_body<2, 3, 0, FLOOR>(a, table, cj, 13); break;
+    default: break;
+  }
+}
+
+// Second kernel of the edit plan: a suspect = {window bits, position | test << 40}.  Every pattern that has the key of the
+// test goes through edit_cost again (here every lane is busy and a key's run of patterns is one contiguous list); what
+// passes leaves as a seed record (pattern index, position) for the automaton (pm_edits_verify), whose last five steps read
+// the ends position - 1 .. position + 3 -- exactly where a match whose frame has field B in place can end.  Records are
+// staged in LDS and join the list in batches (one atomic per few thousand: the list's end is one counter for the grid).
+constexpr int ESTAGE = 4096;                                        // 8-byte records a workgroup stages (32 KiB)
+__global__ __launch_bounds__(256) void pm_pair_edit_resolve(PairArgs a) {
+  __shared__ uint64_t s_rec[ESTAGE];
+  __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_fill, s_valid, s_full;
+  unsigned long long n = *a.susp_count;
+  if (n > a.susp_cap) n = a.susp_cap;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) { s_fill = 0; s_valid = (uint32_t)ESTAGE; }
+  __syncthreads();
+  auto emit = [&](bool ok, uint64_t rec) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(ok);
+    if (bal == 0) return;
+    const int leader = __ffsll((long long)bal) - 1;
+    const uint32_t cnt = (uint32_t)__popcll(bal), mine = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    uint32_t pos = 0;
+    if (lane == leader) pos = atomicAdd(&s_fill, cnt);
+    pos = __builtin_amdgcn_readlane(pos, leader);
+    if (pos + cnt <= (uint32_t)ESTAGE) { if (ok) s_rec[pos + mine] = rec; return; }
+    // no room in this trip's stage (every later reservation of the trip is refused too: s_fill stays above ESTAGE; the
+    // flush takes the slots in front of the first refused position): straight to the list
+    unsigned long long base = 0;
+    if (lane == leader) { atomicMin(&s_valid, pos); base = atomicAdd(a.seed_count, (unsigned long long)cnt); }
+    const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+    if (ok) { const unsigned long long o = (((unsigned long long)bhi << 32) | blo) + mine; if (o < a.seed_cap) a.seed_out[o] = rec; }
+  };
+  auto flush = [&]() __attribute__((always_inline)) {               // block-uniform call
+    __syncthreads();
+    const uint32_t cnt = min(s_fill, s_valid);
+    __syncthreads();
+    if (threadIdx.x == 0) { s_base = cnt ? atomicAdd(a.seed_count, (unsigned long long)cnt) : 0ull; s_fill = 0; s_valid = (uint32_t)ESTAGE; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) if (s_base + i < a.seed_cap) a.seed_out[s_base + i] = s_rec[i];
+    __syncthreads();
+  };
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n; base += stride) {   // block-uniform trip count
+    const unsigned long long i = base + threadIdx.x;
+    uint32_t t0 = 0, t1 = 0, wlo = 0, whi = 0;
+    int var = 0;
+    uint64_t pos40 = 0;
+    if (i < n) {
+      const uint4 r = a.susp[i];
+      if (r.w != 0xffffffffu) {                                     // (a slot its wave reserved and did not need: all ones; a real record's test number is < 14)
+        wlo = r.x; whi = r.y;
+        const uint64_t pw = ((uint64_t)r.w << 32) | r.z;
+        var = (int)((pw >> 40) & 15u);
+        pos40 = pw & 0xffffffffffull;
+        uint32_t key = 0;
+        edit_variant(var, [&](auto A_, auto B_, auto D_) __attribute__((always_inline)) { key = edit_key<decltype(A_)::value, decltype(B_)::value, decltype(D_)::value>(wlo, whi); });
+        const int table = edit_variant_table(var);
+        const uint32_t row = key & 0x7fffu, bit = key >> 15;
+        const uint32_t wd = a.image[(size_t)table * PAIR_BITMAP_WORDS + row];
+        if ((wd >> bit) & 1u) {
+          const uint32_t rank = a.row_base[(size_t)table * (PAIR_BITMAP_WORDS + 1) + row] + (uint32_t)__popc(wd & ((1u << bit) - 1u));
+          const uint32_t *fp = a.first_pat + a.first_off[table];
+          t0 = fp[rank]; t1 = fp[rank + 1];
+        }
+      }
+    }
+    // the key's run of patterns, every lane at its own pace (runs are one or two patterns long but for a few keys)
+    const int table = edit_variant_table(var);
+    const uint32_t *ord = a.order + (size_t)table * a.np, *ol = a.olist + (size_t)table * a.np;
+    while (__ballot(t0 < t1)) {
+      bool ok = false;
+      uint64_t rec = 0;
+      if (t0 < t1) {
+        const uint32_t o = ol[t0];
+        int c = 9;
+        edit_variant(var, [&](auto A_, auto B_, auto D_) __attribute__((always_inline)) { c = edit_cost<decltype(A_)::value, decltype(B_)::value, decltype(D_)::value>(o, wlo, whi); });
+        ok = c <= 2;
+        if (ok) rec = ((uint64_t)ord[t0] << 40) | pos40;
+        ++t0;
+      }
+      emit(ok, rec);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_full = s_fill > (uint32_t)(ESTAGE - 1024);
+    __syncthreads();
+    if (s_full) flush();
+  }
+  flush();
+}
+
 }  // namespace
 
 // ---- host side: tables, launch -------------------------------------------------------------------
 
 std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint32_t> &ids, const Alphabet &alpha, int k,
-                       int eos_code, PairTables *out, int stride_knob) {
+                       int eos_code, PairTables *out, int stride_knob, int slot_patterns) {
+  const size_t SP = slot_patterns == 2 ? 2 : 3;                     // patterns a slot settles (the edit plan compares two: its compare is three times the substitution plan's)
   PairTables &t = *out;
   t = PairTables();
   if (k < 1 || k > 2) return "the pair plan is built for k = 1 and k = 2";
@@ -727,10 +1047,10 @@ std::string pair_build(const std::vector<Pattern> &pats, const std::vector<uint3
         const uint32_t pi = (uint32_t)srt[q];
         ord[q] = pi;
         ol[q] = field_of(t.pat40[pi], fc) | (field_of(t.pat40[pi], fd) << 10);
-        if (q - j < 3) o[q - j] = field_of(t.pat40[pi], fc) | (field_of(t.pat40[pi], fd) << 10);
+        if (q - j < SP) o[q - j] = field_of(t.pat40[pi], fc) | (field_of(t.pat40[pi], fd) << 10);
       }
-      for (size_t q = j2 - j; q < 3; ++q) o[q] = o[0];               // free fields repeat the first pattern
-      if (in_row < KMAX) slot[(size_t)row * ST + in_row] = slot_pack(o[0], o[1], o[2], j2 - j > 3);
+      for (size_t q = std::min(j2 - j, SP); q < 3; ++q) o[q] = o[0];   // free fields repeat the first pattern
+      if (in_row < KMAX) slot[(size_t)row * ST + in_row] = slot_pack(o[0], o[1], o[2], j2 - j > SP);
       ++in_row;
       j = j2;
     }
@@ -806,10 +1126,14 @@ ScanGeometry pair_geometry(const PairDevice &d, int64_t begin, int64_t end) {
 
 hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_t *d_packed, int64_t n, int64_t begin, int64_t end,
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, void *d_susp, unsigned long long *d_susp_count, uint64_t susp_cap,
-                       hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats) {
+                       hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats, int floor_mode,
+                       uint64_t *seed_out, unsigned long long *seed_count, uint64_t seed_cap) {
   if (!d_packed) return hipErrorInvalidValue;
   if (end > n) end = n;
+  if (floor_mode && (d.k != 2 || d.ncombos != 6)) return hipErrorInvalidValue;
+  if (floor_mode == 3 && (!seed_out || !seed_count)) return hipErrorInvalidValue;
   ScanGeometry g = pair_geometry(d, begin, end);
+  if (floor_mode) g.blocks = g.nseg * 14;
   if (geo_out) *geo_out = g;
   if (g.blocks <= 0 || d.np == 0) return hipSuccess;
   PairArgs a;
@@ -830,6 +1154,24 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
   if (!d_susp || !d_susp_count) return hipErrorInvalidValue;
   a.susp = reinterpret_cast<uint4 *>(d_susp); a.susp_count = d_susp_count; a.susp_cap = susp_cap;   // *d_susp_count zeroed by the caller (stream order)
   a.stats = d_stats;
+  a.seed_out = seed_out; a.seed_count = seed_count; a.seed_cap = seed_cap;
+  if (floor_mode) {                                                 // measurement: 14 (pair, displacement) variants, no verify kernel
+    a.ncombos = 14;
+    hipError_t fe;
+    if (floor_mode == 1) {
+      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_floor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_floor<1>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
+    } else if (floor_mode == 2) {
+      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_floor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_floor<2>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
+    } else {                                                        // the edit plan: scan, then suspects -> seed records
+      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_floor<3>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_floor<3>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
+      if ((fe = hipGetLastError()) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_edit_resolve, dim3(16384), dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(pm_pair_scan, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
   hipError_t ce = hipGetLastError();
   if (ce != hipSuccess) return ce;

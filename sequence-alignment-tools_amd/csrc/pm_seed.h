@@ -86,6 +86,7 @@ struct EditStage {
   unsigned long long *d_seed_count = nullptr;     // zeroed by the caller before every launch
   uint64_t seed_cap = 0;
   int tile = 0;
+  bool skip_scan = false;                         // the seed records are there already (pattern index << 40 | position: pm_pair.hip's edit plan): run the verify kernel only
   // exact_bases -k (see pm_bases_verify): per pattern of the whole list (seed-plan pattern ids are 1-based indices into it)
   bool bases = false;
   const uint8_t *b_codes = nullptr, *b_len = nullptr;             // 32 stream codes per pattern, length

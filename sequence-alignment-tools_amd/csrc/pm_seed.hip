@@ -2330,12 +2330,13 @@ hipError_t seed_launch(const SeedDevice &d, const uint8_t *d_text, const uint32_
     // the rare out-of-line paths read the scan's view of the argument block
     ce = hipMemcpyAsync(d.d_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st);
     if (ce != hipSuccess) return ce;
-    if (d.edit_tabulated) hipLaunchKernelGGL(pm_edit_scan, grid, block, SEED_LDS_BYTES, st, sa);
+    if (es->skip_scan) {}
+    else if (d.edit_tabulated) hipLaunchKernelGGL(pm_edit_scan, grid, block, SEED_LDS_BYTES, st, sa);
     else hipLaunchKernelGGL((pm_seed_scan<20, 1, false, true>), grid, block, SEED_LDS_BYTES, st, sa);
     if ((ce = hipGetLastError()) != hipSuccess) return ce;
     EditVerifyArgs v;
     v.a = a;
-    if (d.edit_tabulated) v.a.eidx = d.eidx;
+    if (d.edit_tabulated && !es->skip_scan) v.a.eidx = d.eidx;
     v.seeds = es->d_seeds; v.nseeds = es->d_seed_count; v.seed_cap = es->seed_cap;
     if (es->bases) {
       BasesArgs b;

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
-    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host", "pm_scan_stats",
+    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host", "pm_scan_stats", "pm_measure_pair_edit_floor",
     "pm_comm_unique_id", "pm_comm_create", "pm_comm_gather", "pm_comm_destroy", "pm_comm_last_error",
 ]
 
@@ -101,6 +101,7 @@ def load_library():
         L.pm_final_hits_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.pm_copy_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.pm_scan_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pm_measure_pair_edit_floor.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.pm_pack_time.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
@@ -368,6 +369,12 @@ class PatternMatch:
         self._check(self._L.pm_scan_stats(self._h, v, 8))
         names = ("candidates", "between_stages", "internal_rescans", "blocks", "rounds", "key_hits")
         return {k: int(v[i]) for i, k in enumerate(names)}
+
+    def measure_pair_edit_floor(self, mode):
+        """pm_measure_pair_edit_floor: (kernel ms, suspect records)"""
+        ms, n = C.c_float(), C.c_uint64()
+        self._check(self._L.pm_measure_pair_edit_floor(self._h, mode, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def pack_time(self):
         ms = C.c_float()
