@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B for VERDICT r03 item 3 (GPU box): what would the pair geometry cost as the first stage of the -k 2 plan?
 Runs, on bench.py's 3 Gbp x 100k-primer workload: today's first stage (pm_edit_scan + pm_edits_verify, from a -k 2 handle)
-and the measurement kernels pm_pair_floor<1> / <2> (14 (field pair, displacement) tests per window on the -K 2 tables;
+and the measurement kernels pm_pair_edit_scan<1> / <2> (14 (field pair, displacement) tests per window on the -K 2 tables;
 pm_measure_pair_edit_floor).  Writes one JSON object.    python scripts/edit_pair_floor.py [db_bases] > out.json"""
 import json
 import os

@@ -73,7 +73,7 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
                        pm_hit *d_out, unsigned long long *d_counter, uint64_t cap, void *d_susp, unsigned long long *d_susp_count, uint64_t susp_cap,
                        hipStream_t st, ScanGeometry *geo_out, unsigned long long *d_stats = nullptr, int floor_mode = 0,
                        uint64_t *seed_out = nullptr, unsigned long long *seed_count = nullptr, uint64_t seed_cap = 0);
-// floor_mode 3 = the edit-distance plan on the pair geometry (-k 2): pm_pair_floor<3> (14 tests per window, edit_cost) +
+// floor_mode 3 = the edit-distance plan on the pair geometry (-k 2): pm_pair_edit_scan<3> (14 tests per window, edit_cost) +
 // pm_pair_edit_resolve, seed records (pattern index << 40 | position) into seed_out for pm_edits_verify; tables built
 // with slot_patterns = 2.  floor_mode 1, 2: measurement kernels (pm_measure_pair_edit_floor).
 

@@ -168,10 +168,11 @@ __device__ __host__ __forceinline__ void other_fields(int a, int b, int *c, int 
 //     edits in the region >= i + max(e, u),   u = bases of the region that match at no shift of the set,
 // minimised over the shift sets the remaining budget allows, and the regions' minima add up (the budget is one sum).
 // Mixed sets (an insertion and a deletion in one region) are dominated by the one-sided sets of the same span.
-//   R, base shift 0:            {0}: u | {0,+1}: 1 + u | {0,-1}: max(1, u) | {0,+1,+2}: 2 + u | {0,-1,-2}: max(2, u)
-//   L, base shift -d (mirror):  {0}: u | {+1}: max(1, u) | {-1}: 1 + u | {+1,+2}: max(2, u) | {-1,-2}: 2 + u   (relative to -d)
+//   R, base shift 0:            {0}: u | {0,+1}: 1 + u | {0,-1}: max(1, u) | {0,+1,+2}: 2 + u | {0,-1,-2}: 2 if two_deletions
+//   L, base shift -d (mirror):  {0}: u | {+1}: max(1, u) | {-1}: 1 + u | {+1,+2}: 2 if two_deletions | {-1,-2}: 2 + u   (relative to -d)
 //   M, from -d at A to 0 at B:  d = 0: u | 1 + max(1, u{0,+1}) | 1 + max(1, u{0,-1});  d = 1: 1 + u{-1,0};  d = -1: max(1, u{1,0});
-//                               d = 2: 2 + u{-2,-1,0};  d = -2: max(2, u{2,1,0})
+//                               d = 2: 2 + u{-2,-1,0};  d = -2: 2 if two_deletions
+// (two deletions in one region leave no budget, so their ORDER can be checked: see two_deletions)
 // Window bits: base t of the text, t = -2 .. 21 relative to the 20-base window whose last base is the lane's position, at bits
 // 2 (t + 2) of whi : wlo (2 bits per base; N and end-of-sequence alias to a base there, which only lets more through).
 template <int OFF>
@@ -189,6 +190,18 @@ __device__ __forceinline__ uint32_t mism(uint32_t p, uint32_t wlo, uint32_t whi)
   return (x | (x >> 1)) & (NB == 5 ? 0x155u : 0x55555u);
 }
 enum { REG_L = 0, REG_M = 1, REG_R = 2 };
+// Two DELETIONS in one region use up the budget, so there the order is known and cheap to check: the region's bases form
+// three runs -- at the shift of its low end, one less, two less (towards the high end) -- with the two deleted bases between
+// them.  `lowm`, `midm`, `highm` = mismatch flags at those three shifts.  The longest clean run from the low end and the
+// longest from the high end leave the smallest middle: it must be clean at the middle shift.  (Without this the tier was
+// "at most two bases match at none of three shifts": 14 % of all random ten-base regions, half of all suspects.)
+template <int NB>
+__device__ __forceinline__ bool two_deletions(uint32_t lowm, uint32_t midm, uint32_t highm) {
+  const int lo = __builtin_ctz(lowm | (1u << (2 * NB)));           // first base (its flag bit) that does not match at the low end's shift: a deleted one
+  const int hi = 31 - __builtin_clz(highm | 1u);                    // last base that does not match at the high end's shift (bit 0: none or base 0)
+  const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // flag bits strictly between them (empty when hi <= lo)
+  return (midm & between) == 0;
+}
 // cost of one region: NB bases from pattern base T0 on, base shift BASE, remaining budget BUDGET (shift sets that need more
 // indels than that are not tried -- they would also reach outside the window)
 template <int KIND, int NB, int T0, int BASE, int DSP, int BUDGET>
@@ -206,17 +219,24 @@ __device__ __forceinline__ int region_cost(uint32_t p, uint32_t wlo, uint32_t wh
     else if constexpr (DSP == 1) return 1 + __popc(m0 & mism<NB, T0 - 1>(p, wlo, whi));
     else if constexpr (DSP == -1) return max(1, __popc(m0 & mism<NB, T0 + 1>(p, wlo, whi)));
     else if constexpr (DSP == 2) return 2 + __popc(m0 & mism<NB, T0 - 1>(p, wlo, whi) & mism<NB, T0 - 2>(p, wlo, whi));
-    else return max(2, __popc(m0 & mism<NB, T0 + 1>(p, wlo, whi) & mism<NB, T0 + 2>(p, wlo, whi)));
+    else return two_deletions<NB>(mism<NB, T0 + 2>(p, wlo, whi), mism<NB, T0 + 1>(p, wlo, whi), m0) ? 2 : 9;   // (A's side, the low end, is two ahead)
   } else {
     // R: +1 = insertion, -1 = deletion; L (scanned away from A, towards the pattern's start): +1 = deletion, -1 = insertion
     int c = __popc(m0);
     if constexpr (BUDGET >= 1) {
-      const uint32_t mp1 = m0 & mism<NB, T0 + BASE + 1>(p, wlo, whi), mn1 = m0 & mism<NB, T0 + BASE - 1>(p, wlo, whi);
+      const uint32_t rp1 = mism<NB, T0 + BASE + 1>(p, wlo, whi), rn1 = mism<NB, T0 + BASE - 1>(p, wlo, whi);
+      const uint32_t mp1 = m0 & rp1, mn1 = m0 & rn1;
       const int up = __popc(mp1), dn = __popc(mn1);
       c = min(c, KIND == REG_R ? min(1 + up, max(1, dn)) : min(max(1, up), 1 + dn));
       if constexpr (BUDGET >= 2) {
-        const int up2 = __popc(mp1 & mism<NB, T0 + BASE + 2>(p, wlo, whi)), dn2 = __popc(mn1 & mism<NB, T0 + BASE - 2>(p, wlo, whi));
-        c = min(c, KIND == REG_R ? min(2 + up2, max(2, dn2)) : min(max(2, up2), 2 + dn2));
+        const uint32_t rp2 = mism<NB, T0 + BASE + 2>(p, wlo, whi), rn2 = mism<NB, T0 + BASE - 2>(p, wlo, whi);
+        if constexpr (KIND == REG_R) {                               // two insertions: every base matches at 0, +1 or +2; two deletions: in order, from B's side 0, -1, -2
+          const int ins2 = 2 + __popc(mp1 & rp2);
+          c = min(c, min(ins2, two_deletions<NB>(m0, rn1, rn2) ? 2 : 9));
+        } else {                                                     // in front of A (its high end): deletions raise the shift towards the low end
+          const int ins2 = 2 + __popc(mn1 & rn2);
+          c = min(c, min(ins2, two_deletions<NB>(rp2, rp1, m0) ? 2 : 9));
+        }
       }
     }
     return c;
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(256) void pm_pair_verify(PairArgs a) {
 template <typename F>
 __device__ __forceinline__ void static_for5(F &&f) { for_windows(std::make_integer_sequence<int, 5>(), f); }
 
-// DSP, FLOOR: measurement instantiations (pm_pair_floor below): the pair geometry as the first stage of an
+// DSP, FLOOR: measurement instantiations (pm_pair_edit_scan below): the pair geometry as the first stage of an
 // EDIT-distance plan tests field A displaced by DSP bases against field B (two clean fields of a match with <= 2 edits sit
 // 5 (B - A) + d bases apart, |d| <= 2; 14 (pair, d) tests cover every placement, scripts/edit_pair_cover.py).  FLOOR = 1
 // keeps the substitution compare of the slot's three patterns (a lower bound of such a kernel's cost), FLOOR = 2 runs, for
@@ -817,7 +837,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_scan(PairArgs a) {
 // measurement builds the plan was decided on (profiles/r04_edit_pair_floor.json): they write suspect records and nothing
 // else.  a.ncombos = 14.
 template <int FLOOR>
-__global__ __launch_bounds__(PAIR_THREADS) void pm_pair_floor(PairArgs a) {
+__global__ __launch_bounds__(PAIR_THREADS) void pm_pair_edit_scan(PairArgs a) {
   extern __shared__ uint32_t lds[];
   const int per_super = a.group * a.ncombos;
   const int sc = blockIdx.x / per_super;
@@ -864,16 +884,20 @@ __global__ __launch_bounds__(PAIR_THREADS) void pm_pair_floor(PairArgs a) {
 // passes leaves as a seed record (pattern index, position) for the automaton (pm_edits_verify), whose last five steps read
 // the ends position - 1 .. position + 3 -- exactly where a match whose frame has field B in place can end.  Records are
 // staged in LDS and join the list in batches (one atomic per few thousand: the list's end is one counter for the grid).
-constexpr int ESTAGE = 4096;                                        // 8-byte records a workgroup stages (32 KiB)
+constexpr int ESTAGE = 2048;                                        // 8-byte records a workgroup stages (16 KiB)
+constexpr int EWORK = 3072;                                         // (suspect, pattern of its key's run) items a workgroup queues per trip
 __global__ __launch_bounds__(256) void pm_pair_edit_resolve(PairArgs a) {
   __shared__ uint64_t s_rec[ESTAGE];
+  __shared__ uint4 s_susp[256];                                     // this trip's suspects: {window lo, window hi, position lo, position hi | test << 8}
+  __shared__ uint32_t s_work[EWORK];                                // items: suspect of the trip << 24 | ... no: local suspect id (8 bits) << 24 | offset into the run (24 bits)
+  __shared__ uint32_t s_t0[256];
   __shared__ unsigned long long s_base;
-  __shared__ uint32_t s_fill, s_valid, s_full;
+  __shared__ uint32_t s_fill, s_valid, s_full, s_nwork;
   unsigned long long n = *a.susp_count;
   if (n > a.susp_cap) n = a.susp_cap;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) { s_fill = 0; s_valid = (uint32_t)ESTAGE; }
+  if (threadIdx.x == 0) { s_fill = 0; s_valid = (uint32_t)ESTAGE; s_nwork = 0; }
   __syncthreads();
   auto emit = [&](bool ok, uint64_t rec) __attribute__((always_inline)) {
     const unsigned long long bal = __ballot(ok);
@@ -900,48 +924,63 @@ __global__ __launch_bounds__(256) void pm_pair_edit_resolve(PairArgs a) {
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) if (s_base + i < a.seed_cap) a.seed_out[s_base + i] = s_rec[i];
     __syncthreads();
   };
+  // one (suspect, pattern) item: the pattern's other fields through edit_cost, a seed record when it passes
+  auto item = [&](uint32_t wlo, uint32_t whi, int var, uint64_t pos40, uint32_t t, bool live) __attribute__((always_inline)) {
+    bool ok = false;
+    uint64_t rec = 0;
+    if (live) {
+      const int table = edit_variant_table(var);
+      const uint32_t o = a.olist[(size_t)table * a.np + t];
+      int c = 9;
+      edit_variant(var, [&](auto A_, auto B_, auto D_) __attribute__((always_inline)) { c = edit_cost<decltype(A_)::value, decltype(B_)::value, decltype(D_)::value>(o, wlo, whi); });
+      ok = c <= 2;
+      if (ok) rec = ((uint64_t)a.order[(size_t)table * a.np + t] << 40) | pos40;
+    }
+    emit(ok, rec);
+  };
   for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n; base += stride) {   // block-uniform trip count
     const unsigned long long i = base + threadIdx.x;
-    uint32_t t0 = 0, t1 = 0, wlo = 0, whi = 0;
-    int var = 0;
-    uint64_t pos40 = 0;
-    if (i < n) {
-      const uint4 r = a.susp[i];
-      if (r.w != 0xffffffffu) {                                     // (a slot its wave reserved and did not need: all ones; a real record's test number is < 14)
-        wlo = r.x; whi = r.y;
-        const uint64_t pw = ((uint64_t)r.w << 32) | r.z;
-        var = (int)((pw >> 40) & 15u);
-        pos40 = pw & 0xffffffffffull;
-        uint32_t key = 0;
-        edit_variant(var, [&](auto A_, auto B_, auto D_) __attribute__((always_inline)) { key = edit_key<decltype(A_)::value, decltype(B_)::value, decltype(D_)::value>(wlo, whi); });
-        const int table = edit_variant_table(var);
-        const uint32_t row = key & 0x7fffu, bit = key >> 15;
-        const uint32_t wd = a.image[(size_t)table * PAIR_BITMAP_WORDS + row];
-        if ((wd >> bit) & 1u) {
-          const uint32_t rank = a.row_base[(size_t)table * (PAIR_BITMAP_WORDS + 1) + row] + (uint32_t)__popc(wd & ((1u << bit) - 1u));
-          const uint32_t *fp = a.first_pat + a.first_off[table];
-          t0 = fp[rank]; t1 = fp[rank + 1];
-        }
+    uint32_t t0 = 0, t1 = 0;
+    uint4 r = make_uint4(0, 0, 0, 0xffffffffu);
+    if (i < n) r = a.susp[i];
+    if (r.w != 0xffffffffu) {                                       // (all ones: a slot its wave reserved and did not need; a real record's test number is < 14)
+      const int var = (int)((r.w >> 8) & 15u);
+      uint32_t key = 0;
+      edit_variant(var, [&](auto A_, auto B_, auto D_) __attribute__((always_inline)) { key = edit_key<decltype(A_)::value, decltype(B_)::value, decltype(D_)::value>(r.x, r.y); });
+      const int table = edit_variant_table(var);
+      const uint32_t row = key & 0x7fffu, bit = key >> 15;
+      const uint32_t wd = a.image[(size_t)table * PAIR_BITMAP_WORDS + row];
+      if ((wd >> bit) & 1u) {
+        const uint32_t rank = a.row_base[(size_t)table * (PAIR_BITMAP_WORDS + 1) + row] + (uint32_t)__popc(wd & ((1u << bit) - 1u));
+        const uint32_t *fp = a.first_pat + a.first_off[table];
+        t0 = fp[rank]; t1 = fp[rank + 1];
       }
     }
-    // the key's run of patterns, every lane at its own pace (runs are one or two patterns long but for a few keys)
-    const int table = edit_variant_table(var);
-    const uint32_t *ord = a.order + (size_t)table * a.np, *ol = a.olist + (size_t)table * a.np;
-    while (__ballot(t0 < t1)) {
-      bool ok = false;
-      uint64_t rec = 0;
-      if (t0 < t1) {
-        const uint32_t o = ol[t0];
-        int c = 9;
-        edit_variant(var, [&](auto A_, auto B_, auto D_) __attribute__((always_inline)) { c = edit_cost<decltype(A_)::value, decltype(B_)::value, decltype(D_)::value>(o, wlo, whi); });
-        ok = c <= 2;
-        if (ok) rec = ((uint64_t)ord[t0] << 40) | pos40;
-        ++t0;
-      }
-      emit(ok, rec);
+    // Runs are one pattern long for most suspects and three or more for the flagged ones (keys with more patterns than a
+    // slot holds): lanes walking their own runs idled for most of the trip.  The (suspect, pattern) items of the whole
+    // workgroup go into one queue instead and every thread takes its share.
+    s_susp[threadIdx.x] = r;
+    s_t0[threadIdx.x] = t0;
+    const uint32_t len = t1 - t0;
+    uint32_t at = len ? atomicAdd(&s_nwork, len) : 0u;
+    uint32_t q = 0;
+    for (; q < len && at + q < (uint32_t)EWORK; ++q) s_work[at + q] = ((uint32_t)threadIdx.x << 24) | q;
+    __syncthreads();
+    const uint32_t nw = min(s_nwork, (uint32_t)EWORK);
+    for (uint32_t w0 = 0; w0 < nw; w0 += blockDim.x) {              // block-uniform
+      const uint32_t w = w0 + threadIdx.x;
+      const bool live = w < nw;
+      const uint32_t it = live ? s_work[w] : 0u;
+      const uint4 sr = s_susp[it >> 24];
+      item(sr.x, sr.y, (int)((sr.w >> 8) & 15u), ((uint64_t)(sr.w & 0xffu) << 32) | sr.z, s_t0[it >> 24] + (it & 0xffffffu), live);
+    }
+    // what did not fit the queue (a trip with a key shared by thousands of patterns): its owner walks it
+    {
+      uint32_t t = t0 + q;
+      while (__ballot(t < t1)) { item(r.x, r.y, (int)((r.w >> 8) & 15u), ((uint64_t)(r.w & 0xffu) << 32) | r.z, t, t < t1); if (t < t1) ++t; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) s_full = s_fill > (uint32_t)(ESTAGE - 1024);
+    if (threadIdx.x == 0) { s_full = s_fill > (uint32_t)(ESTAGE - 1024); s_nwork = 0; }
     __syncthreads();
     if (s_full) flush();
   }
@@ -1159,14 +1198,14 @@ hipError_t pair_launch(const PairDevice &d, const uint8_t *d_text, const uint32_
     a.ncombos = 14;
     hipError_t fe;
     if (floor_mode == 1) {
-      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_floor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
-      hipLaunchKernelGGL(pm_pair_floor<1>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
+      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_edit_scan<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_edit_scan<1>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
     } else if (floor_mode == 2) {
-      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_floor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
-      hipLaunchKernelGGL(pm_pair_floor<2>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
+      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_edit_scan<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_edit_scan<2>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
     } else {                                                        // the edit plan: scan, then suspects -> seed records
-      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_floor<3>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
-      hipLaunchKernelGGL(pm_pair_floor<3>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
+      if ((fe = hipFuncSetAttribute(reinterpret_cast<const void *>(pm_pair_edit_scan<3>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES)) != hipSuccess) return fe;
+      hipLaunchKernelGGL(pm_pair_edit_scan<3>, dim3(g.blocks), dim3(PAIR_THREADS), PAIR_LDS_BYTES, st, a);
       if ((fe = hipGetLastError()) != hipSuccess) return fe;
       hipLaunchKernelGGL(pm_pair_edit_resolve, dim3(16384), dim3(256), 0, st, a);
     }
