@@ -126,6 +126,7 @@ def main():
 
         runs = [
             ("primer_match_K2_counts", [os.path.join(HOST, "pm_primer_match"), "-i", db, "-P", os.path.join(d, "primers.txt"), "-K", "2", "-r", "-c", "-v"]),
+            ("primer_match_k2_counts", [os.path.join(HOST, "pm_primer_match"), "-i", db, "-P", os.path.join(d, "primers.txt"), "-k", "2", "-r", "-c", "-v"]),
             ("primer_match_k1_align", [os.path.join(HOST, "pm_primer_match"), "-i", db, "-P", os.path.join(d, "primers.txt"), "-k", "1", "-r", "-A", "%i %r %s %e %d %H\\n", "-v"]),
             ("pcr_match_k1_sts", [os.path.join(HOST, "pm_pcr_match"), "-i", db, "-S", os.path.join(d, "pairs.sts"), "-k", "1", "-M", "1000", "-A", "%I %H %>s %<e %l %>d %<d %r\\n", "-v"]),
         ]

@@ -59,11 +59,16 @@ for name, dst in (("kt_k1e", "k1_edits"), ("kt_k2e", "k2_edits")):
     src = one(os.path.join(G, "lines_" + tag, name, "*", "*kernel_stats.csv"))
     if src:
         shutil.copy(src, os.path.join(P, "%s_kernel_stats_%s.csv" % (tag, dst)))
-for name in ("bench_K2", "bench_k0", "bench_K1", "bench_k1_edits", "bench_k2_edits", "bench_K2_1M", "bench_bitpar_k0_200k", "bench_bitpar_K2_200k", "bench_bitpar_k2_200k"):
+for name in ("bench_K2", "bench_k0", "bench_K1", "bench_k1_edits", "bench_k2_edits", "bench_K2_1M", "bench_bitpar_k0_200k", "bench_bitpar_K2_200k", "bench_bitpar_k2_200k",
+             "bench_K2_scanchunk26", "bench_K2_scanchunk28", "bench_K2_scanchunk30"):
     src = os.path.join(G, "lines_" + tag, name + ".json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, "%s_%s.json" % (tag, name)))
 
+for name in ("edit_pair_floor", "cli_scale_3g"):
+    src = os.path.join(G, "%s_%s.json" % (tag, name))
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(P, "%s_%s.json" % (tag, name)))
 for name in ("stages_k2_edits", "pmc_l2_k2_edits", "sq_k2_edits", "stages_k1_edits", "sq_k1_edits"):
     src = os.path.join(G, "%s_%s.txt" % (tag, name))
     if os.path.exists(src) and os.path.getsize(src):
@@ -80,7 +85,7 @@ for name in ("pmc_fetch_K2", "pmc_write_K2", "pmc_fetch_K0", "pmc_l2_K2"):
     hdr = rows[0]
     kn, cn, cv = hdr.index("Kernel_Name"), hdr.index("Counter_Name"), hdr.index("Counter_Value")
     for x in rows[1:]:
-        if "pm_seed_scan" in x[kn] or "pm_pair_scan" in x[kn]:
+        if "pm_seed_scan" in x[kn] or "pm_pair_scan" in x[kn] or "pm_pair_edit_scan" in x[kn]:
             counters[(name, x[cn])] = counters.get((name, x[cn]), 0.0) + float(x[cv])
 
 entries = []

@@ -17,6 +17,6 @@ run chunk4M PM_SEED_CHUNK=4194304
 run chunk1M PM_SEED_CHUNK=1048576
 for v in $L/libpm_gpu_*.so; do
   n=$(basename $v .so)
-  run $n PM_GPU_LIB=$PWD/$v
-  run ${n}_g1024 PM_GPU_LIB=$PWD/$v PM_SEED_GROUP=1024
+  run $n PM_GPU_LIB=$PWD/$v PM_GPU_LIB_AB=1
+  run ${n}_g1024 PM_GPU_LIB=$PWD/$v PM_GPU_LIB_AB=1 PM_SEED_GROUP=1024
 done

@@ -215,6 +215,11 @@ static void read_knobs(Knobs *k) {
   k->debug = getenv("PM_DEBUG") != nullptr;
 }
 
+extern "C" int pm_prepare_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) return PM_E_HIP;
+  return hipFree(nullptr) == hipSuccess ? PM_OK : PM_E_HIP;         // (forces the runtime's lazy initialisation)
+}
+
 extern "C" int pm_create(const pm_config *cfg, pm_handle **out) {
   if (!cfg || !out) return fail(nullptr, PM_E_INVALID, "pm_create: null argument");
   if (cfg->abi_version != PM_ABI_VERSION) return fail(nullptr, PM_E_INVALID, "pm_create: ABI version mismatch");
@@ -1202,7 +1207,7 @@ static int stream_end_overhang_candidates(pm_handle *h, bool bases) {
         const int len1 = bases ? es : L / 2, len2 = L - len1;
         for (int t = 1; t <= len2; ++t) {
           const int inside = L - t;                                 // pattern characters 0 .. inside-1 lie on the stream's last ones
-          if (inside > need) break;
+          if (inside > need) continue;                              // (more of the pattern than the stream holds: a larger overhang may still fit)
           int lvl = 0;
           bool dead = false;
           for (int i = 0; i < L && !dead; ++i) {

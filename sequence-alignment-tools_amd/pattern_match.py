@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pm_finalize_device", "pm_finalize_device_owned", "pm_align_hits", "pm_align_hits_text",
     "pm_reset", "pm_destroy", "pm_last_error", "pm_selected_semantics", "pm_selected_kernel", "pm_describe",
     "pm_last_kernel_time", "pm_pick_semantics", "pm_measure_stream_read",
-    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host", "pm_scan_stats", "pm_measure_pair_edit_floor",
+    "pm_final_hits_device", "pm_copy_records", "pm_pack_time", "pm_init_host", "pm_scan_stats", "pm_measure_pair_edit_floor", "pm_prepare_device",
     "pm_comm_unique_id", "pm_comm_create", "pm_comm_gather", "pm_comm_destroy", "pm_comm_last_error",
 ]
 
@@ -42,8 +42,16 @@ class _Config(C.Structure):
 
 
 def library_path():
-    # PM_GPU_LIB: A/B measurements of another build of the same library (never a different implementation)
-    return os.environ.get("PM_GPU_LIB") or os.path.join(_CSRC, "libpm_gpu.so")
+    """csrc/libpm_gpu.so.  A/B measurement builds of the same sources (csrc/Makefile VARIANT=...) are loaded only when the
+    caller says so twice: PM_GPU_LIB names a libpm_gpu*.so inside csrc/ AND PM_GPU_LIB_AB=1 is set (scripts/sweep_pair2.sh);
+    a stray environment variable cannot point the product at another file."""
+    alt = os.environ.get("PM_GPU_LIB")
+    if alt and os.environ.get("PM_GPU_LIB_AB") == "1":
+        alt = os.path.abspath(alt)
+        if os.path.dirname(alt) == _CSRC and os.path.basename(alt).startswith("libpm_gpu") and alt.endswith(".so"):
+            return alt
+        raise PmError(-1, "PM_GPU_LIB must name a libpm_gpu*.so inside %s" % _CSRC)
+    return os.path.join(_CSRC, "libpm_gpu.so")
 
 
 def build_library(force=False):

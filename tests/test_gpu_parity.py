@@ -309,6 +309,36 @@ def test_extensions_read_past_the_end_of_the_stream(norm):
                 assert sorted(parts) == want, (norm, esb, eeb, k, len(want), len(parts))
 
 
+@pytest.mark.parametrize("nchars", [11, 15, 19, 23])
+def test_overhang_on_a_stream_shorter_than_the_patterns(nchars):
+    """a stream of fewer characters than a pattern.  The left half (exact_halves) / the mandated first block
+    (exact_bases) is still found inside it and extended over the mapped file's zero padding; the loop over the overhangs
+    must not stop at the first one that does not fit (pm_api.cpp stream_end_overhang_candidates)."""
+    table = b"ACGT\n"
+    tail = "GATTACAGGCTTACCGTCAATGCC"[:nchars - 1]
+    raw = ("\n" + tail).encode()
+    data = synth.normalize(raw, table)
+    text = O.Text(data, table)
+    pats = []
+    for L in (20, 22, 24):
+        for t in range(1, L - L // 2 + 1):
+            if L - t <= len(tail):
+                p = tail[len(tail) - (L - t):] + "A" * t
+                pats += [p, p[:-1] + "C"]
+    pats = list(dict.fromkeys(pats))
+    assert pats
+    for sem, eng, k in [(sat_amd.SEM_EXACT_HALVES, 12, 1), (sat_amd.SEM_EXACT_HALVES, 12, 2)]:
+        want = O.sorted_tuples(O.find_all(text, pats, engine=eng, k=k, indels=False))
+        assert any(h[0] > len(raw) for h in want), (nchars, k)
+        for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED):
+            assert gpu_hits(data, table, pats, sem, k, False, kernel) == want, (nchars, sem, k, kernel)
+    E, F = [8] * len(pats), [0] * len(pats)
+    for k in (1, 2):
+        want = O.sorted_tuples(O.find_all(text, pats, engine=8, k=k, indels=False, esb=E, eeb=F))
+        for kernel in (sat_amd.KERNEL_BITPAR, sat_amd.KERNEL_SEED):
+            assert gpu_hits(data, table, pats, sat_amd.SEM_EXACT_BASES, k, False, kernel, esb=E, eeb=F) == want, (nchars, k, kernel)
+
+
 def test_edit_plan_matches_that_end_with_the_stream():
     """-k on the seed family at the very end of the stream: a match whose last characters need a pattern character
     deleted is seeded by the window one or two positions behind its end, where the stream has no windows
