@@ -16,6 +16,6 @@ python bench.py --steps 2 --warmup 1 --primers 1000000 --no-cpu > $out/bench_K2_
 python bench.py --steps 2 --warmup 1 --kernel bitpar --db-bases 16000000 --k 0 --no-cpu --no-check > $out/bench_bitpar_k0_200k.json 2> $out/bench_bitpar_k0_200k.err && echo "bitpar k0 done"
 python bench.py --steps 2 --warmup 1 --kernel bitpar --db-bases 16000000 --k 2 --no-cpu --no-check > $out/bench_bitpar_K2_200k.json 2> $out/bench_bitpar_K2_200k.err && echo "bitpar K2 done"
 python bench.py --steps 2 --warmup 1 --kernel bitpar --db-bases 16000000 --k 2 --indels 1 --no-cpu --no-check > $out/bench_bitpar_k2_200k.json 2> $out/bench_bitpar_k2_200k.err && echo "bitpar k2 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_k1e -- python bench.py --steps 3 --warmup 1 --k 1 --indels 1 --no-cpu > $out/kt_k1e.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_k2e -- python bench.py --steps 2 --warmup 1 --k 2 --indels 1 --no-cpu > $out/kt_k2e.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_k1e -- python3 bench.py --steps 3 --warmup 1 --k 1 --indels 1 --no-cpu --scan-passes 0 > $out/kt_k1e.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_k2e -- python3 bench.py --steps 3 --warmup 1 --k 2 --indels 1 --no-cpu --scan-passes 0 > $out/kt_k2e.log 2>&1
 echo "all done"
