@@ -883,9 +883,17 @@ extern "C" int pm_describe(const pm_handle *h, char *buf, size_t buflen) {
       if (at < buflen) snprintf(buf + at, buflen - at, " + %s for %zu patterns the seed plan does not take", bitpar_kernel_name(h->scan_k, h->scan_indels), h->nrest);
     }
   }
+  else if (h->kern == PM_KERNEL_SEED && h->edits_dev && h->epair_on) {
+    snprintf(buf, buflen, "kernel=pm_pair_edit_scan+pm_pair_edit_resolve+pm_edits_verify tiles=1 tests=14 fields=2-of-4 x 5 bases, displaced by |d| <= 2 window=20 row_slots=%d slot_patterns=2 chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
+             h->epair.stride, (long long)h->geo.seg_len, h->geo.nseg, h->geo.blocks, h->geo.threads, PAIR_LDS_BYTES);
+    if (h->nrest) {
+      const size_t at = strlen(buf);
+      if (at < buflen) snprintf(buf + at, buflen - at, " + %s for %zu patterns the seed plan does not take", bitpar_kernel_name(h->scan_k, h->scan_indels), h->nrest);
+    }
+  }
   else if (h->kern == PM_KERNEL_SEED) {
     snprintf(buf, buflen, "kernel=%s tiles=%d combos=%d pieces=%d-of-%d x %d bases window=%d slots=%zu chunk=%lld nchunks=%d grid=%d block=%d lds=%d",
-             h->sd.edits && h->epair_on ? "pm_pair_edit_scan+pm_pair_edit_resolve+pm_edits_verify" : h->sd.edits && h->sd.edit_tabulated ? "pm_edit_scan+pm_edits_verify" : h->sd.edits ? "pm_seed_scan+pm_edits_verify" :
+             h->sd.edits && h->sd.edit_tabulated ? "pm_edit_scan+pm_edits_verify" : h->sd.edits ? "pm_seed_scan+pm_edits_verify" :
              h->sd.halves && h->sd.half_ranked ? "pm_half_scan+pm_half_verify" : "pm_seed_scan", 1 + (int)h->sd_more.size(), h->sd.ncombos, h->sd.r, h->sd.k + h->sd.r, h->sd.pb, h->sd.Lw, h->sd.nslots, (long long)h->geo.seg_len, h->geo.nseg,
              h->geo.blocks, h->geo.threads, SEED_LDS_BYTES);
     if (h->nrest) {
@@ -1393,6 +1401,8 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
       if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
       tot += extra.size();
     }
+    if (tot >= ((size_t)1 << 31))
+      return fail(h, PM_E_UNSUPPORTED, "edit-distance plan: 2^31 or more candidate records in one range -- scan the stream in smaller ranges");
     int rc = ensure_sort_workspace(h, tot, false);
     if (rc) return rc;
     const double td0 = now_ms();
@@ -2147,6 +2157,9 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     if (n_out) *n_out = n;
     return PM_OK;
   }
+  // (the device sorts count their items in an int: a hit-dense stream can hand one range more records than that)
+  if (n + h->carry.size() >= ((size_t)1 << 31))
+    return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: 2^31 or more candidate records in one range -- scan the stream in smaller ranges");
   { int rcw = ensure_sort_workspace(h, n + h->carry.size(), true); if (rcw) return rcw; }
   { int rcp = ensure_fpat(h); if (rcp) return rcp; }
   if (cluster_dp) { int rcd = ensure_dp_tables(h); if (rcd) return rcd; }

@@ -235,7 +235,7 @@ def test_edit_distance_three_gbp_100k_primers():
     shift_and_inexact.cc:249-352) at BASELINE size: 100k primers, both strands, 3 Gbp.  Primers that are
     database sites with 0, 1 or 2 random edits (substitution, insertion, deletion) are reported at their
     site with at most that many edits: sites at the very start of the stream, across an edge of the
-    512 Ki-position chunks of pm_edit_scan, beyond 2^31 and at the far end; on a 2 Mbp slice beyond 2^31
+    512 Ki-position chunks of the scan kernel (what 256 MiB ranges get), beyond 2^31 and at the far end; on a 2 Mbp slice beyond 2^31
     the deduplicated candidates equal the bit-parallel family's."""
     n, L, P, k = 3_000_000_000, 22, 100_000, 2
     dev = make_db(n, 81)
@@ -259,7 +259,7 @@ def test_edit_distance_three_gbp_100k_primers():
     pm = engine(allp, k, sat_amd.KERNEL_AUTO, dev, indels=True)
     assert pm.selected() == (sat_amd.SEM_FILTER_BITVEC, sat_amd.KERNEL_SEED)
     hits = all_hits(pm, n, 1 << 28)
-    assert "pm_edit_scan" in pm.describe() and "chunk=524288" in pm.describe(), pm.describe()
+    assert "pm_pair_edit_scan" in pm.describe() and "tests=14" in pm.describe(), pm.describe()      # (round 4: -k 2 on the pair geometry)
     key, kk = hit_index(hits)
     for i, (_, a, sl, d) in enumerate(plant):
         assert found(key, kk, i + 1, a + sl, 2 * k + 1 + d, d), ("planted primer not found", i, a, d)

@@ -815,10 +815,13 @@ def test_edit_distance_seed_plan(seed):
 
 
 @pytest.mark.parametrize("env", [{"PM_EDIT_SCAN": "bloom"}, {"PM_EDIT_TABLE_LOG": "16"}, {"PM_EDIT_TABLE_LOG": "26"},
-                                 {"PM_SEED_CHUNK": "16384", "PM_SEED_GROUP": "3"}, {"PM_SEED_CHUNK": "2097152"}])
+                                 {"PM_SEED_CHUNK": "16384", "PM_SEED_GROUP": "3"}, {"PM_SEED_CHUNK": "2097152"},
+                                 {"PM_EDIT_SCAN": "hash"}, {"PM_EDIT_SCAN": "hash", "PM_EDIT_TABLE_LOG": "16"},
+                                 {"PM_EDIT_SCAN": "hash", "PM_SEED_CHUNK": "16384", "PM_SEED_GROUP": "3"}, {"PM_PAIR_ROW": "3"}])
 def test_edit_distance_plan_switches(env, monkeypatch):
-    """The edit-distance plan's first stage under its switches: the round-1 form (Bloom survivors compacted,
-    PM_EDIT_SCAN=bloom), pm_edit_scan with a tiny and a huge key map (2^16 bits: nearly every Bloom survivor is
+    """The edit-distance plan's first stage under its switches.  -k 2 runs on the pair geometry (pm_pair_edit_scan; round 4)
+    unless PM_EDIT_SCAN says otherwise, -k 1 on the hashed-piece plan: the round-1 form (Bloom survivors compacted,
+    PM_EDIT_SCAN=bloom), round 2's pm_edit_scan (PM_EDIT_SCAN=hash for -k 2) with a tiny and a huge key map (2^16 bits: nearly every Bloom survivor is
     suspicious; 2^26), small chunks with runs of three per combo, 2 Mi chunks.  Thousands of decoy patterns fill the
     filters and the buckets (full 16-slot buckets, several patterns with the same twelve bases); same candidates
     and hits as the oracle (shift_and_inexact.cc:249-352, filter_bitvec.cc:88-177)."""
