@@ -321,14 +321,25 @@ def issue_roofline(args, shard, kms):
         out["valu"] = {"wave_instructions": e["SQ_INSTS_VALU"], "frac_if_all_full_rate": e["SQ_INSTS_VALU"] * 2 / (256 * 4 * cyc),
                        "frac_if_all_half_rate": e["SQ_INSTS_VALU"] * 4 / (256 * 4 * cyc)}
         fr["valu"] = out["valu"]["frac_if_all_half_rate"]
+        # one number instead of the bracket where the kernel's instruction mix has been counted (scripts/isa_histogram.py ->
+        # profiles/r04_isa_hist_pair_scan.txt): wave-instructions x the probe's TIME per instruction (1.02 ns full rate, 1.78 ns
+        # half rate per SIMD at four waves per SIMD: profiles/r03_probe_valu_rate.txt) -- times, so no clock assumption
+        half = {"pm_pair_scan": 0.57, "pm_pair_edit_scan": 0.64}.get(e.get("kernel"))
+        if half is not None:
+            t_ns = (1.0 - half) * (2.45 / 2.4) + half * (4.27 / 2.4)
+            out["valu"]["half_rate_share_static"] = half
+            out["valu"]["frac_at_measured_mix"] = e["SQ_INSTS_VALU"] * t_ns * 1e-9 / (256 * 4) / (kms * 1e-3)
+            fr["valu"] = out["valu"]["frac_at_measured_mix"]
     if e.get("SQ_LDS_IDX_ACTIVE"):
         out["lds"] = {"active_cycles": e["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": e.get("SQ_LDS_BANK_CONFLICT"),
                       "frac": e["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)}
         fr["lds"] = out["lds"]["frac"]
     if e.get("TCP_TCC_READ_REQ_sum"):
         out["l1_l2"] = {"read_requests": e["TCP_TCC_READ_REQ_sum"], "l2_misses": e.get("TCC_MISS_sum"),
-                        "frac": e["TCP_TCC_READ_REQ_sum"] * 2 / (256 * cyc)}
-        fr["l1_l2"] = out["l1_l2"]["frac"]
+                        "frac": e["TCP_TCC_READ_REQ_sum"] * 2 / (256 * cyc),
+                        # the probe's price of one distinct 128-byte line of a wave-level gather: 0.95 CU-ns (r03_probe_tcp_gather.txt)
+                        "frac_at_probe_rate": e["TCP_TCC_READ_REQ_sum"] * 0.95e-9 / 256 / (kms * 1e-3)}
+        fr["l1_l2"] = out["l1_l2"]["frac_at_probe_rate"]
     if fr:
         out["binding"] = max(fr, key=fr.get)
     out.update(staleness(e, kms))
@@ -705,6 +716,8 @@ def main():
     # ranges of --scan-chunk stream bytes, every range drained into the CALLER's (pageable) array, hits sorted by (end, pid).
     # Wall clock from pm_reset to the last record resident in that array; not the headline `value` (which times the
     # sharded step the multi-GPU contract describes), reported beside it.
+    desc = pm.describe()                                            # (the timed steps' launch geometry, not the pm_scan leg's ranges)
+    scan_stats = pm.scan_stats()
     pm_scan_ms, pm_scan_hits, scan_hits_arr = None, None, None
     if not use_dist and args.scan_passes > 0:
         torch.cuda.synchronize()
@@ -774,7 +787,6 @@ def main():
         evs = exch_events[args.warmup:]
         if evs:
             exch_dev_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    scan_stats = pm.scan_stats()
     if scan_stats.get("blocks"):
         # per block of 1024 positions and wave: rounds of the pair kernel's second pass, key hits per lane; key-hit rate per window test
         scan_stats["rounds_per_block"] = scan_stats["rounds"] / scan_stats["blocks"]
@@ -790,7 +802,6 @@ def main():
         shard_bytes = end - begin
         alg_bytes = shard_bytes + 16 * cand_count[0] / max(world, 1)
         achieved = alg_bytes / (kms * 1e-3) / 1e9
-        desc = pm.describe()
         res = {
             "metric": baseline_metric(),
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
