@@ -1139,3 +1139,39 @@ def test_ambiguous_primers_stay_on_the_seed_family(seed):
         assert got == want and len(want) > 20, (seed, k, indels, len(want), len(got))
         assert sat_amd.sorted_tuples(pm.find_all(chunk=997)) == want, (seed, k, indels, "chunked")
         pm.close()
+
+
+def test_round4_introspection_calls():
+    """pm_scan_stats / pm_prepare_device / pm_measure_pair_edit_floor (include/pm_gpu.h, round 4): counters that add up, and the
+    measurement call refuses a handle that is not a -K 2 pair-plan handle."""
+    import ctypes as C
+    L = sat_amd.load_library()
+    assert L.pm_prepare_device(0) == 0
+    rng = np.random.default_rng(31)
+    ents = synth.make_entries(rng, 3, 30000, n_runs=1, repeats=False)
+    pats = synth.make_patterns(rng, ents, 400, length=20, planted=0.5)
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    pm = sat_amd.PatternMatch(k=2, indels=False)
+    for i, p in enumerate(pats):
+        pm.add_pattern(p, i + 1)
+    pm.init(codes, table)
+    cands = pm.scan_candidates(0, codes.size)
+    st = pm.scan_stats()
+    assert st["candidates"] == cands.size and st["between_stages"] >= cands.size // 6 and st["internal_rescans"] == 0, (st, cands.size)
+    ms1, s1 = pm.measure_pair_edit_floor(1)
+    ms2, s2 = pm.measure_pair_edit_floor(2)
+    assert ms1 > 0 and ms2 > 0 and s1 > 0 and s2 > 0, (ms1, ms2, s1, s2, st)
+    assert sat_amd.sorted_tuples(pm.scan_candidates(0, codes.size)) == sat_amd.sorted_tuples(cands)   # the handle is unharmed
+    pm.close()
+    pe = sat_amd.PatternMatch(k=2, indels=True)
+    for i, p in enumerate(pats):
+        pe.add_pattern(p, i + 1)
+    pe.init(codes, table)
+    with pytest.raises(sat_amd.PmError) as ei:
+        pe.measure_pair_edit_floor(1)
+    assert ei.value.code == -2
+    assert "pm_pair_edit_scan" in pe.describe()
+    pe.scan_candidates(0, codes.size, to_host=False)
+    assert pe.scan_stats()["between_stages"] > 0
+    pe.close()
