@@ -1175,3 +1175,36 @@ def test_round4_introspection_calls():
     pe.scan_candidates(0, codes.size, to_host=False)
     assert pe.scan_stats()["between_stages"] > 0
     pe.close()
+
+
+@pytest.mark.parametrize("k,indels", [(0, False), (2, False), (2, True), (1, True)])
+def test_pm_scan_order_with_pattern_ids_in_any_order(k, indels):
+    """pm_scan hands its hits out in (end, pid, k) order.  With pattern ids that grow with the pattern index (what the reference's
+    callers add, primer_match.cc:1105-1107) the order comes from one keys-only radix sort on the device (pm_cluster.hip
+    sort_final_device: key = end | pattern index | k); with ids in any other order the host sorts.  Both must give the oracle's
+    hits in that order, whole and in small ranges."""
+    rng = np.random.default_rng(77 + k)
+    ents = synth.make_entries(rng, 3, 5000, n_runs=2, repeats=True)
+    pats = synth.make_patterns(rng, ents, 200, length=22, planted=0.8, indel_frac=0.3 if indels else 0.0, extras=False)
+    pats = [p for p in pats if 20 <= len(p) <= 32 and set(p) <= set("ACGT")]
+    table = synth.table_for(ents)
+    codes = synth.normalize(synth.stream(ents), table)
+    text = O.Text(codes, table)
+    for ids in (list(range(1, len(pats) + 1)), [5 * (len(pats) - i) + 3 for i in range(len(pats))], [int(x) for x in rng.permutation(len(pats)) * 7 + 11]):
+        eng = O.pick_engine(text, pats, k, indels)
+        want = O.sorted_tuples(O.find_all(text, pats, engine=eng, k=k, indels=indels, ids=ids))
+        pm = sat_amd.PatternMatch(k=k, indels=indels)
+        for p, i in zip(pats, ids):
+            pm.add_pattern(p, i)
+        pm.init(codes, table)
+        for chunk in (1 << 26, 777):
+            pm.reset()
+            got, pos = [], 0
+            while pos < codes.size:
+                e = min(codes.size, pos + chunk)
+                v = pm.scan_view(pos, e)
+                got += list(zip(v["end"].tolist(), v["pid"].tolist(), v["k"].tolist()))
+                pos = e
+            assert got == sorted(got), (k, indels, ids[:3], chunk, "not in (end, pid, k) order")
+            assert got == want, (k, indels, ids[:3], chunk, len(got), len(want))
+        pm.close()
