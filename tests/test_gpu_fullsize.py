@@ -412,3 +412,56 @@ def test_pm_scan_equals_candidates_plus_device_finalize_one_gbp(k, indels):
     pm.scan_view(0, 1 << 26)
     assert pm.scan_candidates(0, n, to_host=False) == ncand
     pm.close()
+
+
+@pytest.mark.parametrize("k,indels", [(2, True), (2, False), (1, True)])
+def test_ranges_across_two_to_the_32_equal_the_oracle(k, indels):
+    """Positions beyond 32 bits through every record format of the plans (the pair-edit plan's suspects carry
+    pos | test << 40, its seeds pattern << 40 | pos; the final sort's key is end | pattern | k): a 4.3e9-byte stream,
+    40,000 patterns; pm_scan over two ranges that meet at 2^32 + 77 must give, for the 200 patterns the oracle is given
+    (filter_bitvec.cc:88-177 / exact_halves.cc:120-197 decide per pattern), exactly the oracle's hits on that window."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import pmoracle as O
+    n, L = (1 << 32) + (1 << 26), 20
+    dev = make_db(n, 91 + k)
+    half = 1 << 19
+    b, e = (1 << 32) - half, (1 << 32) + half
+    margin = 256
+    win = dev[b - margin:e + margin].cpu().numpy()
+    rng = np.random.default_rng(500 + k)
+    few = []
+    for d in range(3):
+        few += [p for p, _, _, _ in plant_edits(win[margin:-margin], rng, 30, L, d)] if indels else [p for p, _, _ in planted(win[margin:-margin], rng, 30, L, min(d, k))]
+    few += random_primers(rng, 100 - len(few), L)
+    few = [p[:32] for p in few]
+    rest = random_primers(rng, 19_900, L)
+    pats = few + rest
+    allp = pats + [sat_amd.reverse_comp(p) for p in pats]
+    pm = engine(allp, k, sat_amd.KERNEL_SEED, dev, indels=indels)
+    if k == 2 and indels:
+        assert "pm_pair_edit_scan" in pm.describe(), pm.describe()
+    pm.reset()
+    pos = 0
+    while pos < b:                                                           # pm_scan's ranges are consecutive from the start of the stream
+        nxt = min(b, pos + (1 << 30))
+        pm.scan_view(pos, nxt)
+        pos = nxt
+    parts = [pm.scan_view(b, (1 << 32) + 77).copy(), pm.scan_view((1 << 32) + 77, e).copy()]
+    got = np.concatenate(parts)
+    P = len(pats)
+    mine = {}                                                                # library pattern id -> oracle pattern id
+    for i in range(100):
+        mine[i + 1] = i + 1
+        mine[P + i + 1] = 100 + i + 1
+    lo, hi = b + 2 * L + 8, e - 2 * L - 8
+    got = sorted((int(x["end"]), mine[int(x["pid"])], int(x["k"])) for x in got if int(x["pid"]) in mine and lo < int(x["end"]) <= hi)
+    sub = few + [sat_amd.reverse_comp(p) for p in few]
+    text = O.Text(win, TABLE)
+    eng = O.pick_engine(text, sub, k, indels)
+    want = sorted((int(end) + b - margin, int(pid), int(kk)) for end, pid, kk in O.sorted_tuples(O.find_all(text, sub, engine=eng, k=k, indels=indels))
+                  if lo < int(end) + b - margin <= hi)
+    assert len(want) >= 60, len(want)
+    assert got == want, (len(got), len(want), [x for x in got if x not in want][:5], [x for x in want if x not in got][:5])
+    pm.close()
