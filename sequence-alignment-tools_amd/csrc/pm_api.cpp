@@ -109,6 +109,10 @@ struct pm_handle {
   float last_ms = 0.f;
   int last_launches = 0;
   unsigned long long internal_rescans = 0;   // scans repeated inside pm_scan_wait since pm_init (an internal buffer was too small)
+  // pm_scan on hit-dense text: a range whose record lists would outgrow dense_bound records is cut in two (and those again)
+  // instead of growing the lists; bound_on is set while pm_scan drives the scan (direct pm_scan_candidates calls keep growing)
+  bool bound_on = false, too_dense = false, dense_mode = false;
+  unsigned long long range_splits = 0;       // ranges pm_scan cut in two since pm_init
   ScanGeometry geo{};
 
   // host stage state
@@ -212,6 +216,7 @@ static void read_knobs(Knobs *k) {
   k->edit_table_log = (int)num("PM_EDIT_TABLE_LOG");
   if (const char *v = getenv("PM_BITPAR_TP")) k->bitpar_tp = atoi(v) != 0;
   k->bitpar_seglen = num("PM_BITPAR_SEGLEN");
+  k->dense_bound = num("PM_DENSE_BOUND");
   k->debug = getenv("PM_DEBUG") != nullptr;
 }
 
@@ -718,7 +723,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     if (h->cap < want) { rc = ensure_capacity(h, want); if (rc) return rc; }
   }
   device_sort_plan(h);
-  h->internal_rescans = 0;
+  h->internal_rescans = 0; h->range_splits = 0; h->dense_mode = false;
   h->inited = true;
   return pm_reset(h);
 }
@@ -1286,6 +1291,19 @@ static int ensure_dp_tables(pm_handle *h) {
 // not the problem and must not be reallocated for it.
 static const int SCAN_AGAIN = 1000;
 
+// Records one list of a scan may hold before pm_scan cuts the range in two instead of growing it (candidates 16 B, suspects
+// 16 B, seed records 8 B, and the finalize stage's sort workspace of ~70 B per candidate): 2^29 by default, PM_DENSE_BOUND
+// for tests.  Always below the 2^31 items the device sorts count in an int.
+static size_t dense_bound(const pm_handle *h) {
+  const long long v = h->knobs.dense_bound;
+  return v > 0 ? (size_t)std::min<long long>(v, (1ll << 31) - 1) : (size_t)1 << 29;
+}
+static int dense_fail(pm_handle *h, const char *what, unsigned long long n) {
+  h->too_dense = true;
+  h->last_count = 0;
+  return fail(h, PM_E_UNSUPPORTED, std::string(what) + ": " + std::to_string(n) + " records in one range -- scan the stream in smaller ranges");
+}
+
 // Waiting for the handle's stream.  (Polling hipStreamQuery instead of hipStreamSynchronize measured no difference
 // around the 15 ms scan kernels: 15.47 against 15.49 ms per step.)
 static hipError_t stream_wait(pm_handle *h) { return hipStreamSynchronize(h->stream); }
@@ -1296,6 +1314,7 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
   const size_t cnt = (size_t)*h->h_counter;
   if (n_out) *n_out = cnt;
+  if (h->bound_on && cnt > dense_bound(h)) return dense_fail(h, "candidate records", cnt);
   if (cnt > h->cap) { h->last_count = 0; return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
   h->last_count = cnt;
   if (h->edits_dev || (h->halves_dev && h->half_ranked_any)) {
@@ -1303,12 +1322,15 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
     unsigned long long worst = 0;
     for (int t = 0; t < 1 + (int)h->sd_more.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
     if (h->knobs.debug) fprintf(stderr, "[pm] %s: %llu seed records (tile with most), seed cap %zu, candidates %zu\n", h->edits_dev ? "edits" : "halves", worst, h->seed_cap, cnt);
+    if (h->bound_on && worst > dense_bound(h)) return dense_fail(h, "seed records of the edit-distance plan", worst);
     if (worst > h->seed_cap) {                                     // grow the seed buffer and tell the caller to scan again
       (void)hipFree(h->d_seeds); h->d_seeds = nullptr;
       h->seed_cap = (size_t)worst + (size_t)worst / 8 + 1024;
       h->last_count = 0;
       return SCAN_AGAIN;
     }
+    if (h->bound_on && h->epair_on && h->edits_dev && h->h_seed_count[260] > dense_bound(h))
+      return dense_fail(h, "suspects of the edit-distance plan", h->h_seed_count[260]);
     if (h->epair_on && h->edits_dev && h->h_seed_count[260] > h->susp_cap) {   // the pair geometry's suspect list between its two kernels
       (void)hipFree(h->d_susp); h->d_susp = nullptr;
       h->susp_cap = (size_t)h->h_seed_count[260] + (size_t)h->h_seed_count[260] / 8 + 1024;
@@ -1334,6 +1356,7 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
     unsigned long long worst = 0;
     for (size_t t = 0; t < h->pair.size(); ++t) worst = std::max(worst, h->h_seed_count[1 + t]);
     if (h->knobs.debug) fprintf(stderr, "[pm] pair plan: %llu suspects (tile with most), capacity %zu, candidates %zu\n", worst, h->susp_cap, cnt);
+    if (h->bound_on && worst > dense_bound(h)) return dense_fail(h, "suspects of the pair plan", worst);
     if (worst > h->susp_cap) {                                     // grow it and tell the caller to scan again
       (void)hipFree(h->d_susp); h->d_susp = nullptr;
       h->susp_cap = (size_t)worst + (size_t)worst / 8 + 1024;
@@ -1401,8 +1424,7 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
       if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
       tot += extra.size();
     }
-    if (tot >= ((size_t)1 << 31))
-      return fail(h, PM_E_UNSUPPORTED, "edit-distance plan: 2^31 or more candidate records in one range -- scan the stream in smaller ranges");
+    if (tot >= ((size_t)1 << 31)) return dense_fail(h, "edit-distance plan, 2^31 or more candidate", tot);
     int rc = ensure_sort_workspace(h, tot, false);
     if (rc) return rc;
     const double td0 = now_ms();
@@ -1483,6 +1505,7 @@ extern "C" int pm_scan_stats(pm_handle *h, uint64_t *out, int n) {
     v[3] = h->h_seed_count[257]; v[4] = h->h_seed_count[258]; v[5] = h->h_seed_count[259];
   }
   v[2] = h->internal_rescans;
+  v[6] = h->range_splits;
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return PM_OK;
 }
@@ -2158,8 +2181,7 @@ static int finalize_device_impl(pm_handle *h, const void *d_cands, size_t n, int
     return PM_OK;
   }
   // (the device sorts count their items in an int: a hit-dense stream can hand one range more records than that)
-  if (n + h->carry.size() >= ((size_t)1 << 31))
-    return fail(h, PM_E_UNSUPPORTED, "pm_finalize_device: 2^31 or more candidate records in one range -- scan the stream in smaller ranges");
+  if (n + h->carry.size() >= ((size_t)1 << 31)) return dense_fail(h, "pm_finalize_device, 2^31 or more candidate", n + h->carry.size());
   { int rcw = ensure_sort_workspace(h, n + h->carry.size(), true); if (rcw) return rcw; }
   { int rcp = ensure_fpat(h); if (rcp) return rcp; }
   if (cluster_dp) { int rcd = ensure_dp_tables(h); if (rcd) return rcd; }
@@ -2336,13 +2358,15 @@ static int align_hits_impl(pm_handle *h, const pm_hit *hits, size_t n, pm_alignm
 // One range of PatternMatch::find_patterns: scan, finalize, final hits in (end, pid, k) order behind whatever the landing
 // buffer still holds.  With a device finalize stage the scan of the range expected next -- the same number of stream
 // bytes, the way the reference's callers walk a stream chunk by chunk -- is already on the GPU when this returns.
-static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
+static int scan_piece(pm_handle *h, int64_t begin, int64_t end) {
   if (begin != h->next_begin) return fail(h, PM_E_INVALID, "pm_scan: ranges must be consecutive (pm_reset to restart)");
   size_t cnt = 0;
   int rc;
+  h->too_dense = false;
   if (h->spec && h->spec_b == begin && h->spec_e == end && h->scan_pending) { h->spec = false; rc = pm_scan_wait(h, &cnt); }
   else rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);       // (drains a speculative scan of another range)
   while (rc == PM_E_OVERFLOW && cnt > h->cap) {                     // grow and redo this range
+    if (cnt > dense_bound(h)) return dense_fail(h, "candidate records", cnt);
     rc = ensure_capacity(h, cnt + cnt / 4 + 1024);
     if (rc) return rc;
     rc = pm_scan_candidates(h, begin, end, nullptr, 0, &cnt);
@@ -2355,7 +2379,7 @@ static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
   if ((h->edits_dev && h->sem == PM_SEM_FILTER_BITVEC && !h->cfg.wildcards && h->pats.size() < ((size_t)1 << 22)) || halves_whole ||
       (device_cluster_plain(h) && h->kern == PM_KERNEL_SEED) || passthrough) {
     // sort, clusters and their DPs on the device; only what it hands back goes through the host stage
-    ScanNext next = {end < h->n, end, std::min<int64_t>(h->n, end + (end - begin))};
+    ScanNext next = {end < h->n && !h->dense_mode, end, std::min<int64_t>(h->n, end + (end - begin))};   // (no guess after a cut: the pieces are not the caller's ranges)
     const OwnedRange all = {0, 0, 0, 0, 0};
     rc = finalize_device_impl(h, nullptr, 0, end, end >= h->n ? PM_FINALIZE_LAST : 0, all, nullptr, 0, nullptr, &next);
     if (rc) return rc;
@@ -2372,6 +2396,34 @@ static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
   }
   h->next_begin = end;
   return PM_OK;
+}
+
+// A range whose lists would outgrow the bound (hit-dense text: DESIGN 7c) is cut in two, and those again: consecutive ranges
+// give the hits of the whole (filter_bitvec.cc:118-121: what a range cannot decide yet waits for the next), so the answer does
+// not change; memory stays bounded and so does the 2^31-item limit of the device sorts.  A failed attempt has changed nothing:
+// every check sits before the finalize stage touches the engine's state.
+static int scan_split(pm_handle *h, int64_t begin, int64_t end, int depth) {
+  h->bound_on = true;
+  const int rc = scan_piece(h, begin, end);
+  h->bound_on = false;
+  if (rc == PM_OK || !h->too_dense) return rc;
+  if (end - begin <= 4096 || depth >= 40) return rc;                // (the message says what was too many)
+  h->dense_mode = true;
+  ++h->range_splits;
+  drain_spec(h);
+  const int64_t mid = begin + (end - begin) / 2;
+  if (h->knobs.debug) fprintf(stderr, "[pm] pm_scan: (%lld, %lld] cut at %lld: %s\n", (long long)begin, (long long)end, (long long)mid, h->err.c_str());
+  const int r1 = scan_split(h, begin, mid, depth + 1);
+  return r1 ? r1 : scan_split(h, mid, end, depth + 1);
+}
+
+static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
+  const size_t before = h->land_n - h->land_pos;                    // (ensure_landing may move the live hits to the front of the buffer)
+  const unsigned long long splits = h->range_splits;
+  const int rc = scan_split(h, begin, end, 0);
+  if (rc == PM_OK && h->range_splits != splits)                     // the pieces' hits, each in order, as one run in (end, pid, k) order
+    sort_hits(h->land + h->land_pos + before, h->land_n - h->land_pos - before);
+  return rc;
 }
 
 extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more) {

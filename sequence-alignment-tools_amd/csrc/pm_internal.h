@@ -44,6 +44,7 @@ struct Knobs {
   int edit_table_log = 0;            // edits: log2 of the key map's bits
   int bitpar_tp = -1;                // force the text-parallel (1) / tile (0) form of the bit-parallel kernel
   long long bitpar_seglen = 0;
+  long long dense_bound = 0;         // PM_DENSE_BOUND: records per list beyond which pm_scan cuts a range in two (0: 2^29)
   bool debug = false;                // PM_DEBUG: stage timings on stderr
 };
 

@@ -375,7 +375,7 @@ class PatternMatch:
         """pm_scan_stats: counters of the last scan (see include/pm_gpu.h)"""
         v = (C.c_uint64 * 8)()
         self._check(self._L.pm_scan_stats(self._h, v, 8))
-        names = ("candidates", "between_stages", "internal_rescans", "blocks", "rounds", "key_hits")
+        names = ("candidates", "between_stages", "internal_rescans", "blocks", "rounds", "key_hits", "range_splits")
         return {k: int(v[i]) for i, k in enumerate(names)}
 
     def measure_pair_edit_floor(self, mode):

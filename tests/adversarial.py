@@ -165,7 +165,7 @@ class knobs:
                 os.environ[name] = self.old[name]
 
 
-def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256):
+def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256, stats=None):
     """the case through the library; sorted (end, pid, k) tuples.  mode 0: find_all over the whole stream; 1: find_all in
     small consecutive ranges (resumable pm_scan); 2: one scan + the device finalize (bench.py's single-rank step); 3: two
     position shards, each finalized on its own with a guard band (bench.py's multi-rank step).  Raises PmError(-2) where
@@ -185,7 +185,13 @@ def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256):
             dev = torch.from_numpy(c["stream"]).cuda()
             pm.init_device(dev.data_ptr(), n, c["table"], keepalive=dev)
         pm.set_capacity(c["cap"])
-        if mode == 0:
+        if mode == 0 and stats is not None:                               # the whole stream as ONE pm_scan range, its span as handed out
+            pm.reset()
+            h = pm.scan_view(0, n).copy()
+            t = list(zip(h["end"].tolist(), h["pid"].tolist(), h["k"].tolist()))
+            assert t == sorted(t), "pm_scan_view: hits not in (end, pid, k) order"
+            stats.update(pm.scan_stats())
+        elif mode == 0:
             h = pm.find_all()
         elif mode == 1:
             h = pm.find_all(chunk=c["chunk"])
