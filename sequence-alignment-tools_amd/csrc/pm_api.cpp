@@ -2407,7 +2407,7 @@ static int scan_split(pm_handle *h, int64_t begin, int64_t end, int depth) {
   const int rc = scan_piece(h, begin, end);
   h->bound_on = false;
   if (rc == PM_OK || !h->too_dense) return rc;
-  if (end - begin <= 4096 || depth >= 40) return rc;                // (the message says what was too many)
+  if (end - begin <= 256 || depth >= 48) return rc;                 // (the message says what was too many)
   h->dense_mode = true;
   ++h->range_splits;
   drain_spec(h);
@@ -2423,6 +2423,7 @@ static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
   const int rc = scan_split(h, begin, end, 0);
   if (rc == PM_OK && h->range_splits != splits)                     // the pieces' hits, each in order, as one run in (end, pid, k) order
     sort_hits(h->land + h->land_pos + before, h->land_n - h->land_pos - before);
+  if (h->range_splits == splits) h->dense_mode = false;             // a range that went through whole: guess the next one again
   return rc;
 }
 

@@ -185,11 +185,16 @@ def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256, stats=None):
             dev = torch.from_numpy(c["stream"]).cuda()
             pm.init_device(dev.data_ptr(), n, c["table"], keepalive=dev)
         pm.set_capacity(c["cap"])
-        if mode == 0 and stats is not None:                               # the whole stream as ONE pm_scan range, its span as handed out
+        if mode == 0 and stats is not None:                               # three equal pm_scan ranges (the second and third guessed and scanned ahead), their spans as handed out
             pm.reset()
-            h = pm.scan_view(0, n).copy()
-            t = list(zip(h["end"].tolist(), h["pid"].tolist(), h["k"].tolist()))
-            assert t == sorted(t), "pm_scan_view: hits not in (end, pid, k) order"
+            parts, pos = [], 0
+            for e in (n // 3, 2 * (n // 3), n):
+                if e > pos:
+                    parts.append(pm.scan_view(pos, e).copy())
+                    t = list(zip(parts[-1]["end"].tolist(), parts[-1]["pid"].tolist(), parts[-1]["k"].tolist()))
+                    assert t == sorted(t), "pm_scan_view: hits not in (end, pid, k) order"
+                    pos = e
+            h = np.concatenate(parts)
             stats.update(pm.scan_stats())
         elif mode == 0:
             h = pm.find_all()
