@@ -110,8 +110,9 @@ int pm_init_device(pm_handle *h, const void *d_text, int64_t n, const uint8_t *t
  * decided (filter_bitvec.cc:118-121 defers the rest to the next call), sorted by (end,pid).
  * Ranges must be consecutive and increasing between pm_reset()s; end == n flushes everything.
  * *more = 1 when out was too small: call again with begin == end to drain.
- * On hit-dense text a range whose internal record lists would outgrow 2^29 records is cut in two
- * by the library, and those again (pm_scan_stats out[6]); the hits are those of the whole range, in the same order. */
+ * On hit-dense text a range whose internal record lists would outgrow 2^30 records is scanned in
+ * pieces by the library (pm_scan_stats out[6] counts the halvings of the piece length); the hits are those of the
+ * whole range, in the same order. */
 int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more);
 
 /* pm_scan without the copy: *hits points at the final hits of the range -- plus any an earlier pm_scan call left
@@ -246,8 +247,8 @@ int pm_last_kernel_time(pm_handle *h, float *ms, int *launches);
  * of the edit / halves plans; the pattern tile with most); out[2] scans the library repeated on its own since pm_init
  * because an internal buffer was too small (pm_last_kernel_time then covers every attempt); with PM_SEED_DEBUG bit 5 set
  * on the pair plan also out[3] blocks of 1024 positions, out[4] rounds of its second pass, out[5] key hits, summed over
- * waves and field pairs; out[6] ranges pm_scan cut in two since pm_init because their record lists would have outgrown
- * its bound (hit-dense text).  n <= 8 values are written. */
+ * waves and field pairs; out[6] times pm_scan halved its piece length since pm_init because a range's record lists would have
+ * outgrown its bound (hit-dense text).  n <= 8 values are written. */
 int pm_scan_stats(pm_handle *h, uint64_t *out, int n);
 
 /* Measurement helper (no reference counterpart; DESIGN.md 4.6 "pair geometry for edits"): on a -K 2 handle of the pair plan,

@@ -64,7 +64,7 @@ def one(bound):
 hits, ms, st, desc = one(args.bound)
 res = {"style": args.style, "k": args.k, "indels": args.indels, "db_bases": args.db_bases, "primers": args.primers, "chunk": args.chunk,
        "pm_scan_ms": ms, "final_hits": int(hits.size), "range_cuts": st["range_splits"], "internal_rescans": st["internal_rescans"],
-       "bound": args.bound or (1 << 29), "plan": desc[:120], "peak_hbm_gb": torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9}
+       "bound": args.bound or (1 << 30), "plan": desc[:120], "peak_hbm_gb": torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9}
 if args.compare_bound:
     h2, ms2, st2, _ = one(args.compare_bound)
     same = h2.size == hits.size and bool((h2["end"] == hits["end"]).all() and (h2["pid"] == hits["pid"]).all() and (h2["k"] == hits["k"]).all())

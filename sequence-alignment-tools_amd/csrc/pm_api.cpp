@@ -112,6 +112,8 @@ struct pm_handle {
   // pm_scan on hit-dense text: a range whose record lists would outgrow dense_bound records is cut in two (and those again)
   // instead of growing the lists; bound_on is set while pm_scan drives the scan (direct pm_scan_candidates calls keep growing)
   bool bound_on = false, too_dense = false, dense_mode = false;
+  int64_t piece_len = 0;                     // pm_scan scans in pieces of at most this many positions (0: whole ranges)
+  unsigned long long last_peak = 0;          // longest record list of the last scan
   unsigned long long range_splits = 0;       // ranges pm_scan cut in two since pm_init
   ScanGeometry geo{};
 
@@ -723,7 +725,7 @@ static int init_common(pm_handle *h, const uint8_t *table, int32_t table_len) {
     if (h->cap < want) { rc = ensure_capacity(h, want); if (rc) return rc; }
   }
   device_sort_plan(h);
-  h->internal_rescans = 0; h->range_splits = 0; h->dense_mode = false;
+  h->internal_rescans = 0; h->range_splits = 0; h->dense_mode = false; h->piece_len = 0;
   h->inited = true;
   return pm_reset(h);
 }
@@ -1292,11 +1294,11 @@ static int ensure_dp_tables(pm_handle *h) {
 static const int SCAN_AGAIN = 1000;
 
 // Records one list of a scan may hold before pm_scan cuts the range in two instead of growing it (candidates 16 B, suspects
-// 16 B, seed records 8 B, and the finalize stage's sort workspace of ~70 B per candidate): 2^29 by default, PM_DENSE_BOUND
+// 16 B, seed records 8 B, and the finalize stage's sort workspace of ~70 B per candidate): 2^30 by default, PM_DENSE_BOUND
 // for tests.  Always below the 2^31 items the device sorts count in an int.
 static size_t dense_bound(const pm_handle *h) {
   const long long v = h->knobs.dense_bound;
-  return v > 0 ? (size_t)std::min<long long>(v, (1ll << 31) - 1) : (size_t)1 << 29;
+  return v > 0 ? (size_t)std::min<long long>(v, (1ll << 31) - 1) : (size_t)1 << 30;
 }
 static int dense_fail(pm_handle *h, const char *what, unsigned long long n) {
   h->too_dense = true;
@@ -1314,6 +1316,12 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
   const size_t cnt = (size_t)*h->h_counter;
   if (n_out) *n_out = cnt;
+  h->last_peak = cnt;
+  if (h->h_seed_count && h->kern == PM_KERNEL_SEED && (h->edits_dev || (h->halves_dev && h->half_ranked_any) || !h->pair.empty())) {
+    const size_t tiles = !h->pair.empty() ? h->pair.size() : 1 + h->sd_more.size();
+    for (size_t t = 0; t < tiles && t < 256; ++t) h->last_peak = std::max(h->last_peak, h->h_seed_count[1 + t]);
+    h->last_peak = std::max(h->last_peak, h->h_seed_count[260]);
+  }
   if (h->bound_on && cnt > dense_bound(h)) return dense_fail(h, "candidate records", cnt);
   if (cnt > h->cap) { h->last_count = 0; return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
   h->last_count = cnt;
@@ -2398,33 +2406,40 @@ static int scan_piece(pm_handle *h, int64_t begin, int64_t end) {
   return PM_OK;
 }
 
-// A range whose lists would outgrow the bound (hit-dense text: DESIGN 7c) is cut in two, and those again: consecutive ranges
-// give the hits of the whole (filter_bitvec.cc:118-121: what a range cannot decide yet waits for the next), so the answer does
-// not change; memory stays bounded and so does the 2^31-item limit of the device sorts.  A failed attempt has changed nothing:
-// every check sits before the finalize stage touches the engine's state.
-static int scan_split(pm_handle *h, int64_t begin, int64_t end, int depth) {
-  h->bound_on = true;
-  const int rc = scan_piece(h, begin, end);
-  h->bound_on = false;
-  if (rc == PM_OK || !h->too_dense) return rc;
-  if (end - begin <= 256 || depth >= 48) return rc;                 // (the message says what was too many)
-  h->dense_mode = true;
-  ++h->range_splits;
-  drain_spec(h);
-  const int64_t mid = begin + (end - begin) / 2;
-  if (h->knobs.debug) fprintf(stderr, "[pm] pm_scan: (%lld, %lld] cut at %lld: %s\n", (long long)begin, (long long)end, (long long)mid, h->err.c_str());
-  const int r1 = scan_split(h, begin, mid, depth + 1);
-  return r1 ? r1 : scan_split(h, mid, end, depth + 1);
-}
-
+// A range whose lists would outgrow the bound (hit-dense text: DESIGN 7c) is not grown for but scanned in pieces: consecutive
+// ranges give the hits of the whole (filter_bitvec.cc:118-121: what a range cannot decide yet waits for the next), so the
+// answer does not change; memory stays bounded and so does the 2^31-item limit of the device sorts.  The piece length halves
+// when a piece was too dense (that attempt is thrown away: every check sits before the finalize stage touches the engine's
+// state), stays for the ranges that follow -- text that was dense a moment ago mostly still is -- and doubles again after
+// a piece whose lists stayed under a quarter of the bound.
 static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
   const size_t before = h->land_n - h->land_pos;                    // (ensure_landing may move the live hits to the front of the buffer)
-  const unsigned long long splits = h->range_splits;
-  const int rc = scan_split(h, begin, end, 0);
-  if (rc == PM_OK && h->range_splits != splits)                     // the pieces' hits, each in order, as one run in (end, pid, k) order
+  int pieces = 0;
+  for (int64_t pos = begin; pos < end;) {
+    const int64_t len = h->piece_len ? std::min<int64_t>(h->piece_len, end - pos) : end - pos;
+    h->dense_mode = len < end - begin;                              // (no guess of the next range while in pieces: they are not the caller's ranges)
+    h->bound_on = true;
+    const int rc = scan_piece(h, pos, pos + len);
+    h->bound_on = false;
+    if (rc != PM_OK) {
+      if (!h->too_dense || len <= 256) return rc;                   // (the message says what was too many)
+      h->piece_len = std::max<int64_t>(256, len / 2);
+      ++h->range_splits;
+      drain_spec(h);
+      if (h->knobs.debug) fprintf(stderr, "[pm] pm_scan: (%lld, %lld] in pieces of %lld: %s\n", (long long)pos, (long long)(pos + len), (long long)h->piece_len, h->err.c_str());
+      continue;
+    }
+    pos += len;
+    ++pieces;
+    if (h->piece_len && h->last_peak < dense_bound(h) / 4) {
+      h->piece_len *= 2;
+      if (h->piece_len >= end - begin) h->piece_len = 0;            // whole ranges again
+    }
+  }
+  if (pieces > 1)                                                   // the pieces' hits, each in order, as one run in (end, pid, k) order
     sort_hits(h->land + h->land_pos + before, h->land_n - h->land_pos - before);
-  if (h->range_splits == splits) h->dense_mode = false;             // a range that went through whole: guess the next one again
-  return rc;
+  h->dense_mode = false;
+  return PM_OK;
 }
 
 extern "C" int pm_scan(pm_handle *h, int64_t begin, int64_t end, pm_hit *out, size_t cap, size_t *n_out, int *more) {

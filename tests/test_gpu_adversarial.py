@@ -71,14 +71,14 @@ def test_adversarial_cases_ran_on_the_seed_family():
 @pytest.mark.parametrize("seed", SEEDS[:120] + [7691])
 def test_adversarial_stream_vs_oracle_with_ranges_cut_by_the_library(seed, monkeypatch):
     """pm_scan cuts a range in two when its record lists would outgrow a bound (pm_api.cpp scan_split; 2^29 records, here
-    PM_DENSE_BOUND = 1500): hit-dense text then costs time, not memory, and never meets the 2^31-item limit of the device
+    PM_DENSE_BOUND = 400): hit-dense text then costs time, not memory, and never meets the 2^31-item limit of the device
     sorts.  Consecutive ranges give the hits of the whole (filter_bitvec.cc:118-121), so nothing may change -- checked
     against the oracle on the cases above, through pm_scan (find_all) whatever the case's own mode."""
     c = A.small_case(seed)
     want = A.oracle_hits(c)
     if want is None:
         pytest.skip("the reference rejects this option set")
-    for bound in (1500, 24000, 400000):                                  # (a case with several records per position cannot get below 1500 in a piece of 256 positions, the smallest the library cuts)
+    for bound in (400, 6000, 400000):                                  # (a case with several records per position cannot get below 400 in a piece of 256 positions, the smallest the library cuts)
         monkeypatch.setenv("PM_DENSE_BOUND", str(bound))
         stats = {}
         try:
@@ -101,4 +101,5 @@ SPLITS = {}
 def test_the_library_did_cut_ranges():
     if len(SPLITS) < 60:
         pytest.skip("the cases did not run in this process")
-    assert sum(1 for v in SPLITS.values() if v > 0) >= 12, sorted(SPLITS.items())[:40]
+    cut = sum(1 for v in SPLITS.values() if v > 0)
+    assert cut >= 8, (cut, sorted(SPLITS.items())[:40])
