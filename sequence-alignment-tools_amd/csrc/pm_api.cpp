@@ -109,12 +109,12 @@ struct pm_handle {
   float last_ms = 0.f;
   int last_launches = 0;
   unsigned long long internal_rescans = 0;   // scans repeated inside pm_scan_wait since pm_init (an internal buffer was too small)
-  // pm_scan on hit-dense text: a range whose record lists would outgrow dense_bound records is cut in two (and those again)
+  // pm_scan on hit-dense text: a range whose record lists would outgrow dense_bound records is scanned in pieces (scan_range)
   // instead of growing the lists; bound_on is set while pm_scan drives the scan (direct pm_scan_candidates calls keep growing)
   bool bound_on = false, too_dense = false, dense_mode = false;
   int64_t piece_len = 0;                     // pm_scan scans in pieces of at most this many positions (0: whole ranges)
   unsigned long long last_peak = 0;          // longest record list of the last scan
-  unsigned long long range_splits = 0;       // ranges pm_scan cut in two since pm_init
+  unsigned long long range_splits = 0;       // times pm_scan halved its piece length since pm_init
   ScanGeometry geo{};
 
   // host stage state
