@@ -131,10 +131,18 @@ def main():
             ("pcr_match_k1_sts", [os.path.join(HOST, "pm_pcr_match"), "-i", db, "-S", os.path.join(d, "pairs.sts"), "-k", "1", "-M", "1000", "-A", "%I %H %>s %<e %l %>d %<d %r\\n", "-v"]),
         ]
         for name, cmd in runs:
-            dt, rc, err = run_timed(cmd, os.path.join(d, name + ".out"))
+            # every command twice, each a new process (HIP start, tables, upload, scan, report: nothing survives between them but the
+            # page cache, which holds the database either way -- it was written a moment ago); wall_s is the faster one, both are kept:
+            # process start and exit on a shared box vary by 0.1 s from run to run
+            walls = []
+            for _ in range(2):
+                dt_i, rc, err_i = run_timed(cmd, os.path.join(d, name + ".out"))
+                walls.append(dt_i)
+                if dt_i == min(walls):
+                    dt, err = dt_i, err_i
             with open(os.path.join(d, name + ".out"), "rb") as f:
                 nlines = sum(1 for _ in f)
-            res["runs"][name] = {"wall_s": dt, "rc": rc, "output_lines": nlines, "gbases_per_s_wall": args.bases / dt / 1e9,
+            res["runs"][name] = {"wall_s": dt, "wall_s_runs": walls, "rc": rc, "output_lines": nlines, "gbases_per_s_wall": args.bases / dt / 1e9,
                                  "phases": [l for l in err.splitlines() if l.startswith("[") or l.startswith("scan")]}
             print(name, "%.2f s" % dt, file=sys.stderr, flush=True)
 

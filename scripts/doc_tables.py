@@ -43,7 +43,7 @@ for label, b, k in rows:
     t = tr.get(key)
     print("| %s | %s | %.1f ms | **%.1f** | %.1f ms = %.0f | %.4f | %s | %s |" % (
         label, kk, d["ms_per_step"], d["value"], d["pm_scan_ms"], d["value_through_pm_scan"], d["roofline"]["frac"],
-        "%.1f GB = %.1f× algorithmic" % (t["traffic_bytes"] / 1e9, t["traffic_bytes"] / d["roofline"]["algorithmic_bytes"]) if t and b in ("K2", "k2_edits") else "--",
+        "%.1f GB = %.1f× algorithmic" % (t["traffic_bytes"] / 1e9, t["traffic_bytes"] / d["roofline"]["algorithmic_bytes"]) if t else "--",
         "%.1e / %.1e" % (cb["value"], ac) if cb.get("value") and ac else "--"))
 print()
 print("| `pm_scan` range | 64 MiB | 256 MiB (the plugin's) | 1 GiB |")
