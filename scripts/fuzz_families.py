@@ -10,7 +10,7 @@ host cluster / halves rules or the stream-edge records is invisible to this form
 reference, on the small cases of tests/adversarial.py (300 .. 8000 characters: what the oracle finishes in well under a
 second) -- the open-ended form of tests/test_gpu_adversarial.py, which keeps 600 fixed seeds in the suite.
 
-    python scripts/fuzz_families.py [seconds] [first_seed] [--oracle]
+    python scripts/fuzz_families.py [seconds] [first_seed] [--oracle [--dense-bound RECORDS]]
 
 Prints one line per case and a summary; exit status 1 on the first difference."""
 import os
@@ -88,7 +88,21 @@ def main_oracle(budget, seed):
         want = A.oracle_hits(c)
         note = ""
         try:
-            got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO)
+            if DENSE_BOUND:
+                # pm_scan's piece-wise form (pm_api.cpp scan_range): every case through pm_scan -- three ranges handed out as
+                # spans, or the case's small chunks -- with a bound so low that ranges are scanned in pieces
+                for bound in (DENSE_BOUND, 16 * DENSE_BOUND, 1 << 30):
+                    os.environ["PM_DENSE_BOUND"] = str(bound)
+                    try:
+                        st = {}
+                        got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO, mode=0, stats=st) if c["mode"] % 2 == 0 else A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO, mode=1)
+                        CUT[0] += st.get("range_splits", 0) > 0
+                        break
+                    except sat_amd.PmError as e2:                      # more records in 256 positions than the bound: not what is tested here
+                        if e2.code != -2 or "smaller ranges" not in str(e2) or bound == 1 << 30:
+                            raise
+            else:
+                got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO)
         except sat_amd.PmError as err:
             if want is None and err.code in (-6, -2):
                 skipped += 1
@@ -110,11 +124,22 @@ def main_oracle(budget, seed):
         seed += 1
     print("oracle form: cases %d (seed family %d, bit-parallel family %d), rejected by reference and library alike %d, failures %d, next seed %d" % (
         cases, fam[sat_amd.KERNEL_SEED], fam[sat_amd.KERNEL_BITPAR], skipped, bad, seed))
+    if DENSE_BOUND:
+        print("with PM_DENSE_BOUND=%d: three-range cases that were scanned in pieces: %d" % (DENSE_BOUND, CUT[0]))
     sys.exit(1 if bad else 0)
 
 
+DENSE_BOUND = 0
+CUT = [0]
+
+
 def main():
+    global DENSE_BOUND
     argv = [a for a in sys.argv[1:] if a != "--oracle"]
+    if "--dense-bound" in argv:
+        i = argv.index("--dense-bound")
+        DENSE_BOUND = int(argv[i + 1])
+        del argv[i:i + 2]
     budget = float(argv[0]) if len(argv) > 0 else 300.0
     seed = int(argv[1]) if len(argv) > 1 else 1000
     if "--oracle" in sys.argv[1:]:
