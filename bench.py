@@ -373,7 +373,7 @@ def main():
     ap.add_argument("--pair-stats", action="store_true", help="count blocks, rounds and key hits in the pair kernel (PM_SEED_DEBUG bit 5; a measurement build of the same kernel)")
     ap.add_argument("--plant-run", type=int, default=0, help="A x this many across the middle of the stream, and the primer A x length with it")
     ap.add_argument("--scan-passes", type=int, default=3, help="timed whole-stream passes through pm_scan itself after the timed region (0 = skip; single GPU only)")
-    ap.add_argument("--scan-chunk", type=int, default=1 << 28, help="stream bytes per pm_scan range (the compiled plugin default)")
+    ap.add_argument("--scan-chunk", type=int, default=1 << 30, help="stream bytes per pm_scan range (the compiled plugin default: 1 GiB)")
     ap.add_argument("--scan-cap", type=int, default=1 << 20, help="records the caller takes per pm_scan call")
     ap.add_argument("--capacity", type=int, default=0, help="initial record capacity (0 = default; small values exercise the grow-and-rescan path)")
     args = ap.parse_args()

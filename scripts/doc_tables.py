@@ -29,7 +29,7 @@ def kstats(name):
 
 rows = [("`-K 2`", "K2", "K2"), ("`-K 1`", "K1", "K1"), ("k = 0", "k0", "K0"), ("`-k 1`", "k1_edits", "k1_edits"), ("`-k 2`", "k2_edits", "k2_edits"), ("`-K 2`, 1M primers", "K2_1M", "K2_1M")]
 tr = {(e["k"], e["indels"]): e for e in (J("traffic_%s.json" % tag) or {"entries": []})["entries"]}
-print("| run | scan kernels, rocprofv3 avg per launch | step | `value`, Gbases/s | through `pm_scan` (256 MiB ranges) | `roofline.frac` of 8 TB/s | fabric traffic per launch | reference CPU, 1 thread / all cores, Gbases/s |")
+print("| run | scan kernels, rocprofv3 avg per launch | step | `value`, Gbases/s | through `pm_scan` (1 GiB ranges) | `roofline.frac` of 8 TB/s | fabric traffic per launch | reference CPU, 1 thread / all cores, Gbases/s |")
 print("|---|---|---|---|---|---|---|---|")
 for label, b, k in rows:
     d = J("%s_bench_%s.json" % (tag, b))
@@ -46,7 +46,7 @@ for label, b, k in rows:
         "%.1f GB = %.1f× algorithmic" % (t["traffic_bytes"] / 1e9, t["traffic_bytes"] / d["roofline"]["algorithmic_bytes"]) if t else "--",
         "%.1e / %.1e" % (cb["value"], ac) if cb.get("value") and ac else "--"))
 print()
-print("| `pm_scan` range | 64 MiB | 256 MiB (the plugin's) | 1 GiB |")
+print("| `pm_scan` range | 64 MiB | 256 MiB | 1 GiB (the plugin's) |")
 print("|---|---|---|---|")
 vals = [J("%s_bench_K2_scanchunk%d.json" % (tag, c)) for c in (26, 28, 30)]
 if all(vals):

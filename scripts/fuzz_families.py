@@ -10,7 +10,7 @@ host cluster / halves rules or the stream-edge records is invisible to this form
 reference, on the small cases of tests/adversarial.py (300 .. 8000 characters: what the oracle finishes in well under a
 second) -- the open-ended form of tests/test_gpu_adversarial.py, which keeps 600 fixed seeds in the suite.
 
-    python scripts/fuzz_families.py [seconds] [first_seed] [--oracle [--dense-bound RECORDS]]
+    python scripts/fuzz_families.py [seconds] [first_seed] [--oracle [--dense-bound RECORDS | --edge-cuts]]
 
 Prints one line per case and a summary; exit status 1 on the first difference."""
 import os
@@ -101,6 +101,13 @@ def main_oracle(budget, seed):
                     except sat_amd.PmError as e2:                      # more records in 256 positions than the bound: not what is tested here
                         if e2.code != -2 or "smaller ranges" not in str(e2) or bound == 1 << 30:
                             raise
+            elif EDGE_CUTS:
+                # pm_scan in ranges of 1 .. 30 positions at both ends of the stream (the host-made records of the stream edges
+                # belong to whatever range holds their end) and a few random cuts in between
+                n = c["n"]
+                r = np.random.default_rng(seed)
+                cuts = list(np.cumsum(r.integers(1, 12, size=8))) + [n - int(x) for x in np.cumsum(r.integers(1, 12, size=8))] + [int(x) for x in r.integers(0, n + 1, size=3)]
+                got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO, cuts=cuts)
             else:
                 got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO)
         except sat_amd.PmError as err:
@@ -130,12 +137,14 @@ def main_oracle(budget, seed):
 
 
 DENSE_BOUND = 0
+EDGE_CUTS = False
 CUT = [0]
 
 
 def main():
-    global DENSE_BOUND
-    argv = [a for a in sys.argv[1:] if a != "--oracle"]
+    global DENSE_BOUND, EDGE_CUTS
+    EDGE_CUTS = "--edge-cuts" in sys.argv[1:]
+    argv = [a for a in sys.argv[1:] if a not in ("--oracle", "--edge-cuts")]
     if "--dense-bound" in argv:
         i = argv.index("--dense-bound")
         DENSE_BOUND = int(argv[i + 1])

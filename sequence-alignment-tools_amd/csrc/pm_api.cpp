@@ -1041,13 +1041,18 @@ static int ensure_sort_workspace(pm_handle *h, size_t n, bool with_out) {
 // every candidate that ends in the first Lw+2k+2 characters is produced here by running the
 // automaton itself (shift_and_inexact.cc:249-352, rows start with l prefix bits :162-164) for each
 // pattern over those few characters; the kernel's records for the same ends are duplicates and
-// leave with the dedup.
-static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
+// leave with the dedup.  Whatever range holds such an end gets them -- a caller's first range may be shorter than that
+// (found by scripts/fuzz_families.py --dense-bound, seed 605103, at the other end of the stream).
+static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *out) {
   const int k = h->cfg.k;
   const int64_t Tfull = std::min<int64_t>(h->n, h->sd.Lw + 2 * k + 2);
-  const int64_t T = std::min<int64_t>(Tfull, h->scan_end);
-  if (T <= 0) return PM_OK;
-  if (T == Tfull && h->start_cached) { *extra = h->start_cache; return PM_OK; }   // same stream, same patterns: computed once
+  const int64_t T = Tfull;
+  if (T <= 0 || h->scan_begin >= Tfull) return PM_OK;
+  if (h->start_cached) {                                            // same stream, same patterns: computed once
+    for (const pm_hit &x : h->start_cache) if (x.end > h->scan_begin && x.end <= h->scan_end) out->push_back(x);
+    return PM_OK;
+  }
+  std::vector<pm_hit> all, *extra = &all;
   uint8_t head[64] = {0};
   if (h->h_text) memcpy(head, h->h_text, (size_t)T);
   else HIP_TRY(h, hipMemcpy(head, h->d_text, (size_t)T, hipMemcpyDeviceToHost));
@@ -1071,13 +1076,14 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
       const uint64_t x2 = (R[2] << 1) | 1, n2 = (x2 & U) | m2 | (n1 << 1) | 1 | n1;
       R[0] = n0; R[1] = n1; R[2] = n2;
       const int lvl = (R[0] & last) ? 0 : (R[1] & last) ? 1 : (k >= 2 && (R[2] & last)) ? 2 : -1;
-      if (lvl >= 0 && t + 1 > h->scan_begin) {
+      if (lvl >= 0) {
         pm_hit x; x.end = t + 1; x.pid = h->inner_ids[j]; x.k = (uint8_t)lvl; x.aux[0] = x.aux[1] = x.aux[2] = 0;
         extra->push_back(x);
       }
     }
   }
-  if (T == Tfull && h->scan_begin == 0) { h->start_cache = *extra; h->start_cached = true; }
+  h->start_cache = all; h->start_cached = true;
+  for (const pm_hit &x : all) if (x.end > h->scan_begin && x.end <= h->scan_end) out->push_back(x);
   return PM_OK;
 }
 
@@ -1091,9 +1097,9 @@ static int edits_start_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
 static int edits_end_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
   const int k = h->cfg.k;
   const int64_t n = h->n;
-  if (h->scan_end < n || n <= 0) return PM_OK;
+  if (h->scan_end <= n - 4 || n <= 0) return PM_OK;                 // (the range that holds such an end gets it: the last range may be shorter than four positions)
   if (h->end_cached) {
-    for (const pm_hit &x : h->end_cache) if (x.end > h->scan_begin) extra->push_back(x);
+    for (const pm_hit &x : h->end_cache) if (x.end > h->scan_begin && x.end <= h->scan_end) extra->push_back(x);
     return PM_OK;
   }
   const int64_t T = std::min<int64_t>(n, 32 + k + 8);
@@ -1131,7 +1137,7 @@ static int edits_end_candidates(pm_handle *h, std::vector<pm_hit> *extra) {
     }
   }
   h->end_cache = all; h->end_cached = true;
-  for (const pm_hit &x : all) if (x.end > h->scan_begin) extra->push_back(x);
+  for (const pm_hit &x : all) if (x.end > h->scan_begin && x.end <= h->scan_end) extra->push_back(x);
   return PM_OK;
 }
 
@@ -1172,7 +1178,8 @@ static int stream_start_candidates(pm_handle *h) {
   }
   h->head_cached = true;
   }
-  const std::vector<pm_hit> &extra = h->head_cache;
+  std::vector<pm_hit> extra;                                        // (the range that holds the end gets the record: a first range may be shorter than a pattern)
+  for (const pm_hit &x : h->head_cache) if (x.end > h->own_begin && x.end <= h->own_end) extra.push_back(x);
   if (extra.empty()) return PM_OK;
   if (h->last_count + extra.size() > h->cap) {
     h->overflow_need = h->last_count + extra.size();
@@ -1375,7 +1382,7 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
   if (h->edits_dev) {
     // records of the stream start (host), then sort + unique on the device: several seeds report each candidate
     size_t tot = cnt;
-    if (h->bases_edits && (h->scan_begin == 0 || h->scan_end >= h->n)) {
+    if (h->bases_edits && (h->own_begin < 56 || h->own_end > h->n - 56)) {
       // exact_bases -k: the records are occurrences of the mandated block, found through windows within k edits of
       // the whole pattern.  A pattern that hangs over the end of the stream has no such window (the extension DP reads
       // code 0 there, see stream_end_overhang_candidates), and at the start of the stream the windows that do not
@@ -1415,16 +1422,15 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
       }
       std::vector<pm_hit> extra;
       for (const pm_hit &x : h->edge_cache) {
-        if (!((x.end <= E && h->scan_begin == 0) || (x.end > n - E && h->scan_end >= n))) continue;   // the edge(s) this scan covers
-        if (x.end > h->own_begin && x.end <= h->own_end) extra.push_back(x);
+        if (x.end > h->own_begin && x.end <= h->own_end) extra.push_back(x);     // (whatever range holds the end)
       }
       if (tot + extra.size() > h->cap) { h->last_count = 0; if (n_out) *n_out = tot + extra.size(); return fail(h, PM_E_OVERFLOW, "candidate buffer too small (pm_set_capacity)"); }
       if (!extra.empty()) HIP_TRY(h, hipMemcpy(h->d_cands + tot, extra.data(), extra.size() * sizeof(pm_hit), hipMemcpyHostToDevice));
       tot += extra.size();
     }
-    if ((h->scan_begin == 0 || h->scan_end >= h->n) && !h->bases_edits) {   // (exact_bases: the records are block seeds, not automaton ends)
+    if (!h->bases_edits) {                                          // (exact_bases: the records are block seeds, not automaton ends)
       std::vector<pm_hit> extra;
-      int rc = h->scan_begin == 0 ? edits_start_candidates(h, &extra) : PM_OK;
+      int rc = edits_start_candidates(h, &extra);
       if (rc) return rc;
       rc = edits_end_candidates(h, &extra);
       if (rc) return rc;
@@ -1445,7 +1451,7 @@ static int scan_wait_once(pm_handle *h, size_t *n_out) {
     h->last_launches += 3;
     return PM_OK;
   }
-  if (h->kern == PM_KERNEL_SEED && h->scan_begin == 0 && h->seed_k > 0 &&
+  if (h->kern == PM_KERNEL_SEED && h->own_begin < 32 && h->seed_k > 0 &&
       (h->sem == PM_SEM_FILTER_BITVEC || h->sem == PM_SEM_SHIFT_AND_INEXACT)) {
     int rc = stream_start_candidates(h);
     if (rc) { if (rc == PM_E_OVERFLOW && n_out) *n_out = h->overflow_need; return rc; }

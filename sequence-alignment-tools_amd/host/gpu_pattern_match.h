@@ -97,7 +97,7 @@ class GpuPatternMatch {
   bool sharded_done_ = false;
   std::vector<unsigned char> owned_;            // stream drained from a producer without c_str()
   int64_t n_ = 0;
-  int64_t chunk_ = (int64_t)1 << 28;
+  int64_t chunk_ = (int64_t)1 << 30;
   unsigned long next_id_ = 0;
 };
 

@@ -7,7 +7,7 @@
 #include "util.h"            // reference: timestamp()
 
 gpu_pattern_match::gpu_pattern_match(int kernel, unsigned int k, char eos, bool wc, bool tn, bool indels, bool dna_mut)
-    : h_(0), n_(0), base_(0), chunk_((FILE_POSITION_TYPE)1 << 28) {
+    : h_(0), n_(0), base_(0), chunk_((FILE_POSITION_TYPE)1 << 30) {
   if (dna_mut) {
     timestamp("Fatal error: DNA mutation scoring is not available in the GPU engine.");
     exit(1);
@@ -73,9 +73,10 @@ bool gpu_pattern_match::find_patterns(CharacterProducer &cp, pattern_hit_vector 
   // The reference's callers loop `while (find_patterns(...) || !l.empty())` and read cp.pos() right
   // after the call as "scanned up to here" (primer_match.cc:1118-1121, pcr_match.cc:952,1057): every
   // hit returned ends at or before cp.pos(), hits arrive in non-decreasing end order.
-  // One range of chunk_ stream bytes per pm_scan_view call (256 MiB unless PM_GPU_CHUNK says otherwise: a first hit
-  // after ~1 ms of scanning, a dozen progress reports per 3 Gbp); the records are pushed straight from the library's
-  // buffer, and while they are the GPU already scans the next range (include/pm_gpu.h, pm_scan_view).
+  // One range of chunk_ stream bytes per pm_scan_view call (1 GiB unless PM_GPU_CHUNK says otherwise: a first hit after
+  // ~5 ms of scanning; 0.27 ms of finalize and host round trip per range are 6 % of a 3 Gbp pass at this size and 20 % in
+  // 256 MiB ranges; on hit-dense text the library scans a range in pieces by itself, include/pm_gpu.h); the records are
+  // pushed straight from the library's buffer, and while they are the GPU already scans the next range (pm_scan_view).
   long unsigned got = 0;
   for (;;) {
     const FILE_POSITION_TYPE begin = cp.pos() - base_;

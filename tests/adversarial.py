@@ -165,7 +165,7 @@ class knobs:
                 os.environ[name] = self.old[name]
 
 
-def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256, stats=None):
+def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256, stats=None, cuts=None):
     """the case through the library; sorted (end, pid, k) tuples.  mode 0: find_all over the whole stream; 1: find_all in
     small consecutive ranges (resumable pm_scan); 2: one scan + the device finalize (bench.py's single-rank step); 3: two
     position shards, each finalized on its own with a guard band (bench.py's multi-rank step).  Raises PmError(-2) where
@@ -185,7 +185,19 @@ def gpu_hits(c, kernel=sat_amd.KERNEL_SEED, mode=None, guard=256, stats=None):
             dev = torch.from_numpy(c["stream"]).cuda()
             pm.init_device(dev.data_ptr(), n, c["table"], keepalive=dev)
         pm.set_capacity(c["cap"])
-        if mode == 0 and stats is not None:                               # three equal pm_scan ranges (the second and third guessed and scanned ahead), their spans as handed out
+        if cuts is not None:                                              # pm_scan ranges that end at the given stream positions
+            pm.reset()
+            parts, pos = [], 0
+            # (exact_halves / exact_bases extend a seed found inside the range to an end that may lie beyond it, as the reference's
+            # wrappers do around their inner engine's position: exact_halves.cc:153-167; the other engines' ends are window ends)
+            strict = pm.selected()[0] not in (sat_amd.SEM_EXACT_HALVES, sat_amd.SEM_EXACT_BASES)
+            for e in sorted(set(min(max(int(x), 0), n) for x in cuts) | {n}):
+                if e > pos:
+                    parts.append(pm.scan_view(pos, e).copy())
+                    assert not strict or parts[-1].size == 0 or (int(parts[-1]["end"].max()) <= e), "pm_scan: a hit beyond the scanned-to position"
+                    pos = e
+            h = np.concatenate(parts)
+        elif mode == 0 and stats is not None:                               # three equal pm_scan ranges (the second and third guessed and scanned ahead), their spans as handed out
             pm.reset()
             parts, pos = [], 0
             for e in (n // 3, 2 * (n // 3), n):

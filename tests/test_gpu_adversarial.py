@@ -103,3 +103,24 @@ def test_the_library_did_cut_ranges():
         pytest.skip("the cases did not run in this process")
     cut = sum(1 for v in SPLITS.values() if v > 0)
     assert cut >= 8, (cut, sorted(SPLITS.items())[:40])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS[120:260] + [605103])
+def test_adversarial_stream_vs_oracle_in_tiny_ranges_at_the_stream_edges(seed):
+    """The records the host makes for the two ends of the stream -- ends the kernels' whole windows cannot seed: the first
+    L + 2k + 2 positions and the last four of the edit-distance plans (pm_api.cpp edits_start_candidates / edits_end_candidates),
+    the prefix-deleted ends of -K (stream_start_candidates, shift_and_inexact.cc:162-164), the block occurrences of exact_bases
+    -k -- belong to whatever range holds the end, however short the caller's first and last ranges are; no hit may lie beyond
+    the scanned-to position (primer_match.cc:1121).  Seed 605103: found with the library's own pieces (fuzz_families
+    --dense-bound), a last piece of one position."""
+    c = A.small_case(seed)
+    want = A.oracle_hits(c)
+    if want is None:
+        pytest.skip("the reference rejects this option set")
+    n = c["n"]
+    got = A.gpu_hits(c, kernel=sat_amd.KERNEL_AUTO, cuts=[1, 3, 7, 19, 33, 60, n // 2, n - 61, n - 30, n - 5, n - 3, n - 2, n - 1])
+    if got != want:
+        sg, sw = set(got), set(want)
+        raise AssertionError("%s [%s]: %d hits, oracle %d; only GPU %s; only oracle %s" % (
+            A.describe(c), c["kernel_desc"][:50], len(got), len(want), sorted(sg - sw)[:6], sorted(sw - sg)[:6]))
