@@ -2437,7 +2437,7 @@ static int scan_range(pm_handle *h, int64_t begin, int64_t end) {
     }
     pos += len;
     ++pieces;
-    if (h->piece_len && h->last_peak < dense_bound(h) / 4) {
+    if (h->piece_len && len == h->piece_len && h->last_peak < dense_bound(h) / 4) {   // (a full piece: the short one at the end of a range says nothing)
       h->piece_len *= 2;
       if (h->piece_len >= end - begin) h->piece_len = 0;            // whole ranges again
     }
