@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """pm_scan on hit-dense text at database size: a stream of bench.py's hard styles, every primer cut from it,
-scanned in 256 MiB ranges; the library cuts a range in two where its record lists would outgrow its bound
-(pm_api.cpp scan_split).  Prints one JSON line: time, hits, cuts; with --compare-bound B a second pass with that bound
+scanned in 256 MiB ranges; the library scans a range in pieces where its record lists would outgrow its bound
+(pm_api.cpp scan_range).  Prints one JSON line: time, hits, halvings of the piece length; with --compare-bound B a second pass with that bound
 (PM_DENSE_BOUND, read in pm_create) must give the same hits.
     python scripts/dense_split.py --style tandem --k 2 --indels 1 --db-bases 300000000"""
 import argparse

@@ -70,10 +70,10 @@ def test_adversarial_cases_ran_on_the_seed_family():
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS[:120] + [7691])
 def test_adversarial_stream_vs_oracle_with_ranges_cut_by_the_library(seed, monkeypatch):
-    """pm_scan cuts a range in two when its record lists would outgrow a bound (pm_api.cpp scan_split; 2^29 records, here
+    """pm_scan scans a range in pieces when its record lists would outgrow a bound (pm_api.cpp scan_range; 2^30 records, here
     PM_DENSE_BOUND = 400): hit-dense text then costs time, not memory, and never meets the 2^31-item limit of the device
     sorts.  Consecutive ranges give the hits of the whole (filter_bitvec.cc:118-121), so nothing may change -- checked
-    against the oracle on the cases above, through pm_scan (find_all) whatever the case's own mode."""
+    against the oracle on the cases above, through pm_scan in three ranges whatever the case's own mode."""
     c = A.small_case(seed)
     want = A.oracle_hits(c)
     if want is None:
